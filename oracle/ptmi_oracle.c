@@ -1,0 +1,860 @@
+/* ptmi_oracle.c — CPU restatement of the reference's per-pixel render loop.
+ *
+ * TEST INFRASTRUCTURE ONLY: this file is the checker, never the product.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  libptmi.so (the product) has no CPU render path at all.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - geometry layer (vector math, Ray, Triangle/Quad::intersect, centroid,
+ *     BVHBuilder, Scene::intersect_bvh_optimized / intersect_linear, Sensor)
+ *     is PINNED: tests/test_oracle_vs_ref.py compares this file bit-for-bit
+ *     with the reference's own headers compiled from /root/reference by
+ *     oracle/Makefile into oracle/_ref/ (g++, no stand-in headers).
+ *   - OBJ/MTL loader, integrator(), sampleCosineHemisphere, the render kernel's
+ *     tone-map and the cuRAND XORWOW generator cannot be compiled here
+ *     (file_manager.h / grid.h include <cuda_runtime.h>, <curand_kernel.h>,
+ *     absent from this image; no stand-ins are written).  They are restated
+ *     below from the source text and pinned only by the known answers the
+ *     survey recorded from the reference (primitive counts, BVH
+ *     dump, camera-ray hits).  RNG parity with real cuRAND: UNPINNED.
+ *
+ * All file:line citations are relative to /root/reference/include/.
+ * Compile with -ffp-contract=off: every float expression below is written in
+ * the reference's evaluation order and must not be fused or re-associated.
+ */
+#define _GNU_SOURCE
+#include "ptmi_oracle.h"
+#include "../include/ptmi_math.h"
+
+#include <ctype.h>
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* core/vector.h                                                             */
+/* ------------------------------------------------------------------------ */
+typedef struct { float e[3]; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {{x, y, z}}; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); }   /* vector.h:148-153 */
+static inline v3 vsub(v3 a, v3 b) { return V(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); }   /* vector.h:155-160 */
+static inline v3 vmul(v3 a, v3 b) { return V(a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2]); }   /* vector.h:162-167 */
+static inline v3 vdivv(v3 a, v3 b) { return V(a.e[0] / b.e[0], a.e[1] / b.e[1], a.e[2] / b.e[2]); }  /* vector.h:169-174 */
+static inline v3 vscale(float t, v3 v) { return V(t * v.e[0], t * v.e[1], t * v.e[2]); }              /* vector.h:177-187 */
+static inline v3 vneg(v3 a) { return V(-a.e[0], -a.e[1], -a.e[2]); }                                  /* vector.h:56-60 */
+/* vector.h:189-195 and :90-94: division by a scalar multiplies by T k = 1.0 / t
+ * (binary64 quotient rounded to binary32). */
+static inline float recip_via_double(float t) { return (float)(1.0 / (double)t); }
+static inline v3 vdivs(v3 v, float t) { float k = recip_via_double(t); return V(v.e[0] * k, v.e[1] * k, v.e[2] * k); }
+static inline float vdot(v3 a, v3 b) {                                                                /* vector.h:198-203 */
+    float sum = 0; sum += a.e[0] * b.e[0]; sum += a.e[1] * b.e[1]; sum += a.e[2] * b.e[2]; return sum;
+}
+static inline float vlen2(v3 a) { float sum = 0; sum += a.e[0] * a.e[0]; sum += a.e[1] * a.e[1]; sum += a.e[2] * a.e[2]; return sum; } /* vector.h:97-101 */
+/* vector.h:103-105: sqrt() of a float; whether it resolves to the float or the
+ * double overload the rounded result is the same (sqrt double rounding is innocuous). */
+static inline float vlen(v3 a) { return sqrtf(vlen2(a)); }
+static inline v3 vunit(v3 v) { return vdivs(v, vlen(v)); }                                            /* vector.h:205-208 */
+static inline v3 vcross(v3 a, v3 b) {                                                                 /* vector.h:211-218 */
+    return V(a.e[1] * b.e[2] - a.e[2] * b.e[1],
+             (-(a.e[0] * b.e[2] - a.e[2] * b.e[0])),
+             a.e[0] * b.e[1] - a.e[1] * b.e[0]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* scene data                                                                */
+/* ------------------------------------------------------------------------ */
+enum { PRIM_TRIANGLE = 0, PRIM_QUAD = 1 };  /* primitive.h:15-18 */
+
+typedef struct {
+    int type;
+    v3 v[4];            /* tri: v0 v1 v2 ; quad: v00 v10 v11 v01 */
+    v3 bsdf, normal, Le;
+} oprim;
+
+typedef struct {        /* bvh.h:63-72 */
+    v3 bmin, bmax;
+    int left_child, right_child, prim_count;
+} onode;
+
+struct po_scene {
+    oprim* prims; int n_prims;
+    onode* nodes; int n_nodes, cap_nodes;
+    int* indices;
+};
+
+/* ------------------------------------------------------------------------ */
+/* triangle.h / quad.h constructors used by the loader                       */
+/* ------------------------------------------------------------------------ */
+static oprim make_tri5(v3 v0, v3 v1, v3 v2, v3 bsdf, v3 normal) {   /* triangle.h:49-62 */
+    oprim p; memset(&p, 0, sizeof p);
+    p.type = PRIM_TRIANGLE; p.v[0] = v0; p.v[1] = v1; p.v[2] = v2; p.v[3] = V(0, 0, 0);
+    p.bsdf = bsdf; p.normal = normal; p.Le = V(0, 0, 0);
+    return p;
+}
+static oprim make_tri4(v3 v0, v3 v1, v3 v2, v3 bsdf) {              /* triangle.h:23-47: geometric normal */
+    v3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+    return make_tri5(v0, v1, v2, bsdf, vunit(vcross(e1, e2)));
+}
+static oprim make_quad(v3 v00, v3 v10, v3 v11, v3 v01, v3 bsdf) {   /* quad.h:23-47 */
+    oprim p; memset(&p, 0, sizeof p);
+    p.type = PRIM_QUAD; p.v[0] = v00; p.v[1] = v10; p.v[2] = v11; p.v[3] = v01;
+    v3 e1 = vsub(v10, v00), e2 = vsub(v01, v00);
+    p.bsdf = bsdf; p.normal = vunit(vcross(e1, e2)); p.Le = V(0, 0, 0);
+    return p;
+}
+
+/* ------------------------------------------------------------------------ */
+/* utils/file_manager.h: loadMTL (39-79), loadOBJ (93-273)                    */
+/* ------------------------------------------------------------------------ */
+typedef struct { char name[256]; v3 bsdf, Le; } omat;
+typedef struct { omat* m; int n, cap; } omatmap;
+
+static void matmap_set(omatmap* mm, const char* name, const omat* val) {   /* std::map operator[] = */
+    for (int i = 0; i < mm->n; i++)
+        if (strcmp(mm->m[i].name, name) == 0) { mm->m[i].bsdf = val->bsdf; mm->m[i].Le = val->Le; return; }
+    if (mm->n == mm->cap) { mm->cap = mm->cap ? mm->cap * 2 : 8; mm->m = (omat*)realloc(mm->m, sizeof(omat) * mm->cap); }
+    mm->m[mm->n] = *val;
+    snprintf(mm->m[mm->n].name, sizeof mm->m[mm->n].name, "%s", name);
+    mm->n++;
+}
+static const omat* matmap_find(const omatmap* mm, const char* name) {
+    for (int i = 0; i < mm->n; i++) if (strcmp(mm->m[i].name, name) == 0) return &mm->m[i];
+    return NULL;
+}
+
+/* istream >> std::string: skip whitespace, read until whitespace */
+static const char* next_token(const char* p, char* tok, size_t cap) {
+    while (*p && isspace((unsigned char)*p)) p++;
+    size_t n = 0;
+    while (*p && !isspace((unsigned char)*p)) { if (n + 1 < cap) tok[n++] = *p; p++; }
+    tok[n] = 0;
+    return p;
+}
+/* istream >> float (three of them); returns 0 on failure like the stream's fail state */
+static int read_floats(const char** pp, float* out, int n) {
+    const char* p = *pp;
+    for (int i = 0; i < n; i++) {
+        while (*p && isspace((unsigned char)*p)) p++;
+        char* end;
+        float f = strtof(p, &end);
+        if (end == p) { for (int j = i; j < n; j++) out[j] = 0.0f; *pp = p; return 0; }
+        out[i] = f; p = end;
+    }
+    *pp = p; return 1;
+}
+
+static char* read_line(FILE* f, char** buf, size_t* cap) {   /* std::getline: strips '\n' only */
+    ssize_t n = getline(buf, cap, f);
+    if (n < 0) return NULL;
+    if (n > 0 && (*buf)[n - 1] == '\n') (*buf)[n - 1] = 0;
+    return *buf;
+}
+
+static void load_mtl(const char* filename, omatmap* out) {   /* file_manager.h:39-79 */
+    out->n = 0;
+    FILE* f = fopen(filename, "r");
+    if (!f) { fprintf(stderr, "[oracle] Warning: Could not open MTL file: %s\n", filename); return; }
+    char cur_name[256] = ""; omat cur; cur.bsdf = V(0.8f, 0.8f, 0.8f); cur.Le = V(0, 0, 0);   /* :27-30 */
+    char* line = NULL; size_t cap = 0; char tok[256];
+    while (read_line(f, &line, &cap)) {
+        const char* p = next_token(line, tok, sizeof tok);
+        if (strcmp(tok, "newmtl") == 0) {
+            if (cur_name[0]) matmap_set(out, cur_name, &cur);
+            next_token(p, cur_name, sizeof cur_name);
+            cur.bsdf = V(0.8f, 0.8f, 0.8f); cur.Le = V(0, 0, 0);
+        } else if (strcmp(tok, "Kd") == 0) {
+            float c[3]; read_floats(&p, c, 3); cur.bsdf = V(c[0], c[1], c[2]);
+        } else if (strcmp(tok, "Ke") == 0) {
+            float c[3]; read_floats(&p, c, 3); cur.Le = V(c[0], c[1], c[2]);
+        }
+    }
+    if (cur_name[0]) matmap_set(out, cur_name, &cur);
+    free(line); fclose(f);
+}
+
+/* one face-vertex token: "v", "v/vt", "v//vn", "v/vt/vn" (file_manager.h:162-190).
+ * size_t extraction accepts a leading sign and wraps, as num_get does. */
+static int parse_face_token(const char* tok, size_t* v_out, size_t* vn_out) {
+    const char* p = tok; char* end;
+    size_t v = 0, vn = 0;
+    if (!(isdigit((unsigned char)*p) || ((*p == '-' || *p == '+') && isdigit((unsigned char)p[1])))) return 0;
+    v = (size_t)strtoull(p, &end, 10); p = end;
+    if (*p == '/') {
+        p++;
+        if (*p == '/') {
+            p++;
+            if (isdigit((unsigned char)*p) || ((*p == '-' || *p == '+') && isdigit((unsigned char)p[1]))) vn = (size_t)strtoull(p, &end, 10);
+        } else if (isdigit((unsigned char)*p) || ((*p == '-' || *p == '+') && isdigit((unsigned char)p[1]))) {
+            (void)strtoull(p, &end, 10); p = end;   /* vt */
+            if (*p == '/') {
+                p++;
+                if (isdigit((unsigned char)*p) || ((*p == '-' || *p == '+') && isdigit((unsigned char)p[1]))) vn = (size_t)strtoull(p, &end, 10);
+            }
+        }
+    }
+    *v_out = v; *vn_out = vn; return 1;
+}
+
+typedef struct { oprim* p; int n, cap; } primvec;
+static void pv_push(primvec* pv, const oprim* p) {
+    if (pv->n == pv->cap) { pv->cap = pv->cap ? pv->cap * 2 : 64; pv->p = (oprim*)realloc(pv->p, sizeof(oprim) * pv->cap); }
+    pv->p[pv->n++] = *p;
+}
+
+static int load_obj(const char* obj_filename, primvec* out) {   /* file_manager.h:93-273 */
+    FILE* f = fopen(obj_filename, "r");
+    if (!f) { fprintf(stderr, "[oracle] Error: Cannot open OBJ file: %s\n", obj_filename); return 0; }
+    char path_base[4096] = "";
+    {   /* :100-104 */
+        const char* s1 = strrchr(obj_filename, '/'); const char* s2 = strrchr(obj_filename, '\\');
+        const char* s = s1 > s2 ? s1 : s2;
+        if (s) { size_t n = (size_t)(s - obj_filename) + 1; if (n >= sizeof path_base) n = sizeof path_base - 1; memcpy(path_base, obj_filename, n); path_base[n] = 0; }
+    }
+    v3* verts = NULL; size_t nv = 0, capv = 0;
+    v3* norms = NULL; size_t nn = 0, capn = 0;
+    omatmap mats = {0, 0, 0};
+    omat cur; cur.bsdf = V(0.8f, 0.8f, 0.8f); cur.Le = V(0, 0, 0); cur.name[0] = 0;
+    char* line = NULL; size_t cap = 0; char tok[1024];
+    while (read_line(f, &line, &cap)) {
+        if (line[0] == 0 || line[0] == '#' || line[0] == 'o' || line[0] == 's') continue;   /* :120 */
+        const char* p = next_token(line, tok, sizeof tok);
+        if (strcmp(tok, "v") == 0) {
+            float c[3]; if (!read_floats(&p, c, 3)) continue;
+            if (nv == capv) { capv = capv ? capv * 2 : 256; verts = (v3*)realloc(verts, sizeof(v3) * capv); }
+            verts[nv++] = V(c[0], c[1], c[2]);
+        } else if (strcmp(tok, "vn") == 0) {
+            float c[3]; if (!read_floats(&p, c, 3)) continue;
+            if (nn == capn) { capn = capn ? capn * 2 : 256; norms = (v3*)realloc(norms, sizeof(v3) * capn); }
+            norms[nn++] = vunit(V(c[0], c[1], c[2]));   /* :141 */
+        } else if (strcmp(tok, "mtllib") == 0) {
+            char name[1024], full[8192];
+            next_token(p, name, sizeof name);
+            snprintf(full, sizeof full, "%s%s", path_base, name);
+            load_mtl(full, &mats);
+        } else if (strcmp(tok, "usemtl") == 0) {
+            char name[256]; next_token(p, name, sizeof name);
+            const omat* m = matmap_find(&mats, name);
+            if (m) cur = *m; else { cur.bsdf = V(0.8f, 0.8f, 0.8f); cur.Le = V(0, 0, 0); }   /* :151-156 */
+        } else if (strcmp(tok, "f") == 0) {
+            size_t vi[64], ni[64]; int cnt = 0;
+            for (;;) {
+                p = next_token(p, tok, sizeof tok);
+                if (!tok[0]) break;
+                size_t v, vn;
+                if (!parse_face_token(tok, &v, &vn)) continue;   /* :167-170: warn, skip token */
+                if (cnt < 64) { vi[cnt] = v; ni[cnt] = vn; }
+                cnt++;
+            }
+            if (cnt == 3) {   /* :193-219 */
+                if (vi[0] == 0 || vi[1] == 0 || vi[2] == 0 || vi[0] > nv || vi[1] > nv || vi[2] > nv) continue;
+                v3 v0 = verts[vi[0] - 1], v1 = verts[vi[1] - 1], v2 = verts[vi[2] - 1];
+                v3 nrm;
+                if (ni[0] != 0 && ni[0] <= nn) nrm = norms[ni[0] - 1];
+                else nrm = vunit(vcross(vsub(v1, v0), vsub(v2, v0)));
+                oprim t = make_tri5(v0, v1, v2, cur.bsdf, nrm);
+                t.Le = cur.Le;
+                pv_push(out, &t);
+            } else if (cnt == 4) {   /* :221-246 */
+                if (vi[0] == 0 || vi[1] == 0 || vi[2] == 0 || vi[3] == 0 ||
+                    vi[0] > nv || vi[1] > nv || vi[2] > nv || vi[3] > nv) continue;
+                oprim q = make_quad(verts[vi[0] - 1], verts[vi[1] - 1], verts[vi[2] - 1], verts[vi[3] - 1], cur.bsdf);
+                if (ni[0] != 0 && ni[0] <= nn) q.normal = norms[ni[0] - 1];
+                q.Le = cur.Le;
+                pv_push(out, &q);
+            }
+            /* other arities: warned about and dropped (:247-250) */
+        }
+    }
+    free(line); free(verts); free(norms); free(mats.m); fclose(f);
+    return out->n > 0;   /* :254-257 */
+}
+
+/* application_state.h:323-365 */
+static void convert_quads_to_triangles(primvec* pv) {
+    primvec out = {0, 0, 0};
+    for (int i = 0; i < pv->n; i++) {
+        const oprim* q = &pv->p[i];
+        if (q->type == PRIM_QUAD) {
+            oprim t1 = make_tri4(q->v[0], q->v[1], q->v[2], q->bsdf); t1.Le = q->Le; pv_push(&out, &t1);
+            oprim t2 = make_tri4(q->v[0], q->v[2], q->v[3], q->bsdf); t2.Le = q->Le; pv_push(&out, &t2);
+        } else pv_push(&out, q);
+    }
+    free(pv->p); *pv = out;
+}
+
+/* rendering/form_factors.h:475-574 */
+static v3 vhalf(v3 a, v3 b) { v3 s = vadd(a, b); return V(s.e[0] * 0.5f, s.e[1] * 0.5f, s.e[2] * 0.5f); }
+static void subdivide_primitives(primvec* pv, int levels) {
+    for (int it = 0; it < levels; it++) {
+        primvec out = {0, 0, 0};
+        for (int i = 0; i < pv->n; i++) {
+            const oprim* p = &pv->p[i];
+            if (p->type == PRIM_TRIANGLE) {   /* :479-499 */
+                v3 m0 = vhalf(p->v[0], p->v[1]), m1 = vhalf(p->v[1], p->v[2]), m2 = vhalf(p->v[2], p->v[0]);
+                oprim s[4] = { make_tri4(p->v[0], m0, m2, p->bsdf), make_tri4(m0, p->v[1], m1, p->bsdf),
+                               make_tri4(m1, p->v[2], m2, p->bsdf), make_tri4(m0, m1, m2, p->bsdf) };
+                for (int k = 0; k < 4; k++) { s[k].Le = p->Le; pv_push(&out, &s[k]); }
+            } else {                          /* :501-522 */
+                v3 m01 = vhalf(p->v[0], p->v[1]), m12 = vhalf(p->v[1], p->v[2]);
+                v3 m23 = vhalf(p->v[2], p->v[3]), m30 = vhalf(p->v[3], p->v[0]);
+                v3 c = vadd(vadd(vadd(p->v[0], p->v[1]), p->v[2]), p->v[3]);
+                c = V(c.e[0] * 0.25f, c.e[1] * 0.25f, c.e[2] * 0.25f);
+                oprim s[4] = { make_quad(p->v[0], m01, c, m30, p->bsdf), make_quad(m01, p->v[1], m12, c, p->bsdf),
+                               make_quad(c, m12, p->v[2], m23, p->bsdf), make_quad(m30, c, m23, p->v[3], p->bsdf) };
+                for (int k = 0; k < 4; k++) { s[k].Le = p->Le; pv_push(&out, &s[k]); }
+            }
+        }
+        free(pv->p); *pv = out;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* rendering/bvh.h: BVHBuilder (76-219)                                       */
+/* ------------------------------------------------------------------------ */
+static v3 prim_centroid(const oprim* p) {   /* primitive.h:92-98 */
+    if (p->type == PRIM_TRIANGLE) return vdivs(vadd(vadd(p->v[0], p->v[1]), p->v[2]), 3.0f);
+    v3 s = vadd(vadd(vadd(p->v[0], p->v[1]), p->v[2]), p->v[3]);
+    return V(s.e[0] * 0.25f, s.e[1] * 0.25f, s.e[2] * 0.25f);
+}
+typedef struct { v3 mn, mx; } aabb;
+static aabb aabb_empty(void) { aabb b; b.mn = V(1e30f, 1e30f, 1e30f); b.mx = V(-1e30f, -1e30f, -1e30f); return b; }   /* bvh.h:17 */
+static aabb aabb_merge(aabb a, aabb b) {   /* bvh.h:30-35 */
+    aabb r;
+    for (int k = 0; k < 3; k++) { r.mn.e[k] = fminf(a.mn.e[k], b.mn.e[k]); r.mx.e[k] = fmaxf(a.mx.e[k], b.mx.e[k]); }
+    return r;
+}
+static aabb compute_bounds(const po_scene* s, int start, int end) {   /* bvh.h:108-148 */
+    aabb bounds = aabb_empty();
+    const float eps = 1e-6f;
+    for (int i = start; i < end; i++) {
+        const oprim* p = &s->prims[s->indices[i]];
+        aabb b;
+        for (int k = 0; k < 3; k++) {
+            float mn, mx;
+            if (p->type == PRIM_TRIANGLE) {
+                mn = fminf(fminf(p->v[0].e[k], p->v[1].e[k]), p->v[2].e[k]);
+                mx = fmaxf(fmaxf(p->v[0].e[k], p->v[1].e[k]), p->v[2].e[k]);
+            } else {
+                mn = fminf(fminf(p->v[0].e[k], p->v[1].e[k]), fminf(p->v[2].e[k], p->v[3].e[k]));
+                mx = fmaxf(fmaxf(p->v[0].e[k], p->v[1].e[k]), fmaxf(p->v[2].e[k], p->v[3].e[k]));
+            }
+            b.mn.e[k] = mn - eps; b.mx.e[k] = mx + eps;
+        }
+        bounds = aabb_merge(bounds, b);
+    }
+    return bounds;
+}
+static int push_node(po_scene* s) {
+    if (s->n_nodes == s->cap_nodes) { s->cap_nodes = s->cap_nodes ? s->cap_nodes * 2 : 64; s->nodes = (onode*)realloc(s->nodes, sizeof(onode) * s->cap_nodes); }
+    onode* n = &s->nodes[s->n_nodes];
+    n->bmin = V(1e30f, 1e30f, 1e30f); n->bmax = V(-1e30f, -1e30f, -1e30f);
+    n->left_child = -1; n->right_child = -1; n->prim_count = 0;   /* bvh.h:69 */
+    return s->n_nodes++;
+}
+static int build_recursive(po_scene* s, int start, int end) {   /* bvh.h:154-218 */
+    int node_idx = push_node(s);
+    aabb bbox = compute_bounds(s, start, end);
+    int count = end - start;
+    if (count <= 4) {
+        onode* n = &s->nodes[node_idx];
+        n->bmin = bbox.mn; n->bmax = bbox.mx; n->left_child = start; n->prim_count = count;
+        return node_idx;
+    }
+    aabb cb = aabb_empty();
+    for (int i = start; i < end; i++) {
+        v3 c = prim_centroid(&s->prims[s->indices[i]]);
+        aabb one; one.mn = c; one.mx = c;
+        cb = aabb_merge(cb, one);
+    }
+    int best_axis = 0;
+    v3 extent = vsub(cb.mx, cb.mn);
+    if (extent.e[1] > extent.e[0]) best_axis = 1;
+    if (extent.e[2] > extent.e[best_axis]) best_axis = 2;
+    if (extent.e[best_axis] < 1e-6f) {
+        onode* n = &s->nodes[node_idx];
+        n->bmin = bbox.mn; n->bmax = bbox.mx; n->left_child = start; n->prim_count = count;
+        return node_idx;
+    }
+    float split_pos = (cb.mn.e[best_axis] + cb.mx.e[best_axis]) * 0.5f;   /* bvh.h:21-23 center() */
+    int mid = start;
+    for (int i = start; i < end; i++) {
+        if (prim_centroid(&s->prims[s->indices[i]]).e[best_axis] < split_pos) {
+            int t = s->indices[i]; s->indices[i] = s->indices[mid]; s->indices[mid] = t;
+            mid++;
+        }
+    }
+    if (mid == start || mid == end) mid = start + count / 2;
+    int left_idx = build_recursive(s, start, mid);
+    int right_idx = build_recursive(s, mid, end);
+    onode* n = &s->nodes[node_idx];
+    n->bmin = bbox.mn; n->bmax = bbox.mx;
+    n->left_child = left_idx; n->right_child = right_idx; n->prim_count = 0;
+    return node_idx;
+}
+static void build_bvh(po_scene* s) {   /* bvh.h:83-104 */
+    s->indices = (int*)malloc(sizeof(int) * (size_t)(s->n_prims > 0 ? s->n_prims : 1));
+    for (int i = 0; i < s->n_prims; i++) s->indices[i] = i;
+    s->nodes = NULL; s->n_nodes = 0; s->cap_nodes = 0;
+    build_recursive(s, 0, s->n_prims);
+}
+
+/* ------------------------------------------------------------------------ */
+/* scene API                                                                 */
+/* ------------------------------------------------------------------------ */
+po_scene* po_scene_load(const char* path, int subdivision_count, int convert_quads) {   /* application_state.h:367-464 */
+    const char* dot = strrchr(path, '.');
+    if (!dot) return NULL;
+    char ext[16]; size_t n = 0;
+    for (const char* p = dot; *p && n + 1 < sizeof ext; p++) ext[n++] = (char)tolower((unsigned char)*p);
+    ext[n] = 0;
+    if (strcmp(ext, ".obj") != 0) { fprintf(stderr, "[oracle] ERROR: Unsupported file format: %s\n", ext); return NULL; }
+    primvec pv = {0, 0, 0};
+    if (!load_obj(path, &pv)) { free(pv.p); return NULL; }
+    if (convert_quads) convert_quads_to_triangles(&pv);
+    if (subdivision_count > 0) subdivide_primitives(&pv, subdivision_count);
+    po_scene* s = (po_scene*)calloc(1, sizeof *s);
+    s->prims = pv.p; s->n_prims = pv.n;
+    build_bvh(s);
+    return s;
+}
+
+po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
+                               const float* normal, const float* bsdf, const float* Le) {
+    po_scene* s = (po_scene*)calloc(1, sizeof *s);
+    s->prims = (oprim*)calloc((size_t)(n > 0 ? n : 1), sizeof(oprim)); s->n_prims = n;
+    for (int i = 0; i < n; i++) {
+        oprim* p = &s->prims[i];
+        p->type = type[i];
+        for (int k = 0; k < 4; k++) p->v[k] = V(verts[(i * 4 + k) * 3], verts[(i * 4 + k) * 3 + 1], verts[(i * 4 + k) * 3 + 2]);
+        p->normal = V(normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]);
+        p->bsdf = V(bsdf[i * 3], bsdf[i * 3 + 1], bsdf[i * 3 + 2]);
+        p->Le = V(Le[i * 3], Le[i * 3 + 1], Le[i * 3 + 2]);
+    }
+    build_bvh(s);
+    return s;
+}
+void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s); }
+int po_scene_num_prims(const po_scene* s) { return s->n_prims; }
+int po_scene_num_nodes(const po_scene* s) { return s->n_nodes; }
+void po_scene_get_prims(const po_scene* s, int* type, float* verts, float* normal, float* bsdf, float* Le) {
+    for (int i = 0; i < s->n_prims; i++) {
+        const oprim* p = &s->prims[i];
+        type[i] = p->type;
+        for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) verts[(i * 4 + k) * 3 + c] = p->v[k].e[c];
+        for (int c = 0; c < 3; c++) { normal[i * 3 + c] = p->normal.e[c]; bsdf[i * 3 + c] = p->bsdf.e[c]; Le[i * 3 + c] = p->Le.e[c]; }
+    }
+}
+void po_scene_get_bvh(const po_scene* s, float* bmin, float* bmax, int* left, int* right, int* count, int* indices) {
+    for (int i = 0; i < s->n_nodes; i++) {
+        for (int c = 0; c < 3; c++) { bmin[i * 3 + c] = s->nodes[i].bmin.e[c]; bmax[i * 3 + c] = s->nodes[i].bmax.e[c]; }
+        left[i] = s->nodes[i].left_child; right[i] = s->nodes[i].right_child; count[i] = s->nodes[i].prim_count;
+    }
+    for (int i = 0; i < s->n_prims; i++) indices[i] = s->indices[i];
+}
+
+/* ------------------------------------------------------------------------ */
+/* rendering/sensor.h                                                        */
+/* ------------------------------------------------------------------------ */
+static void update_camera(v3 origin, v3 lookat, v3 vup, float vfov, float aspect, po_camera_frame* out) {   /* sensor.h:38-51 */
+    float theta = (float)((double)vfov * PTMI_PI_D / (double)180.0f);   /* vfov * M_PI / 180.0f with double M_PI */
+    float half_height = (float)ptmi_tan_d((double)(theta / 2.0f));
+    float half_width = aspect * half_height;
+    v3 w = vunit(vsub(origin, lookat));
+    v3 u = vunit(vcross(vup, w));
+    v3 v = vcross(w, u);
+    v3 llc = vsub(vsub(vsub(origin, vscale(half_width, u)), vscale(half_height, v)), w);
+    v3 hor = vscale(2 * half_width, u);
+    v3 ver = vscale(2 * half_height, v);
+    for (int k = 0; k < 3; k++) {
+        out->origin[k] = origin.e[k]; out->lower_left_corner[k] = llc.e[k];
+        out->horizontal[k] = hor.e[k]; out->vertical[k] = ver.e[k];
+    }
+}
+void po_camera_frame_setup(const po_camera* cam, int width, int height, po_camera_frame* out) {
+    v3 origin = V(cam->origin[0], cam->origin[1], cam->origin[2]);
+    v3 lookat = V(cam->lookat[0], cam->lookat[1], cam->lookat[2]);
+    v3 vup = V(cam->vup[0], cam->vup[1], cam->vup[2]);
+    float aspect = (float)width / (float)height;   /* application_state.h:108 */
+    if (cam->orbit) {   /* sensor.h:16-29 radius from the constructor's lookfrom; :56-67 orbit */
+        float radius = vlen(vsub(origin, lookat));
+        float yawRad = (float)((double)cam->yaw_deg * PTMI_PI_D / (double)180.0f);     /* ToRadian, sensor.h:11 */
+        float pitchRad = (float)((double)cam->pitch_deg * PTMI_PI_D / (double)180.0f);
+        float sy, cy, sp, cp;
+        ptmi_sincosf(yawRad, &sy, &cy); ptmi_sincosf(pitchRad, &sp, &cp);
+        origin.e[0] = lookat.e[0] + radius * cp * cy;
+        origin.e[1] = lookat.e[1] + radius * sp;
+        origin.e[2] = lookat.e[2] + radius * cp * sy;
+    }
+    update_camera(origin, lookat, vup, cam->vfov_deg, aspect, out);
+}
+typedef struct { v3 o, d; } ray_t;
+static ray_t make_ray(v3 origin, v3 direction) { ray_t r; r.o = origin; r.d = vunit(direction); return r; }   /* ray.h:9-12 */
+static ray_t camera_get_ray(const po_camera_frame* c, float u, float v) {   /* sensor.h:31-33 */
+    v3 o = V(c->origin[0], c->origin[1], c->origin[2]);
+    v3 llc = V(c->lower_left_corner[0], c->lower_left_corner[1], c->lower_left_corner[2]);
+    v3 hor = V(c->horizontal[0], c->horizontal[1], c->horizontal[2]);
+    v3 ver = V(c->vertical[0], c->vertical[1], c->vertical[2]);
+    return make_ray(o, vsub(vadd(vadd(llc, vscale(u, hor)), vscale(v, ver)), o));
+}
+void po_camera_ray(const po_camera_frame* c, float u, float v, float o[3], float d[3]) {
+    ray_t r = camera_get_ray(c, u, v);
+    for (int k = 0; k < 3; k++) { o[k] = r.o.e[k]; d[k] = r.d.e[k]; }
+}
+
+/* ------------------------------------------------------------------------ */
+/* cuRAND XORWOW (third-party, NVIDIA CUDA Toolkit curand_kernel.h; not in    */
+/* /root/reference, version unpinned by the reference's CMakeLists.txt:2).    */
+/* Published algorithm restated: Marsaglia xorwow + Weyl sequence; curand_init */
+/* seed scrambling; subsequence = 2^67 steps, skipped with GF(2) matrix powers;*/
+/* curand_uniform = x * 2^-32 + 2^-33 in (0,1].                                */
+/* Call sites: integrator.h:63-64, 210, 279, 384-385.  UNPINNED vs real cuRAND.*/
+/* ------------------------------------------------------------------------ */
+typedef struct { uint32_t row[160][5]; } xmat;
+static xmat g_jump[32];          /* g_jump[k] = T^(2^67 * 2^k) */
+static int g_jump_ready = 0;
+
+static void xorwow_step_v(uint32_t v[5]) {
+    uint32_t t = v[0] ^ (v[0] >> 2);
+    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+static void xmat_apply(const xmat* m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 32; j++)
+            if (in[i] & (1u << j)) { const uint32_t* row = m->row[i * 32 + j]; for (int k = 0; k < 5; k++) r[k] ^= row[k]; }
+    for (int k = 0; k < 5; k++) out[k] = r[k];
+}
+static void xmat_square(const xmat* m, xmat* out) {
+    for (int b = 0; b < 160; b++) xmat_apply(m, m->row[b], out->row[b]);
+}
+static void init_jump_tables(void) {
+    if (g_jump_ready) return;
+    xmat* a = (xmat*)malloc(sizeof(xmat)); xmat* b = (xmat*)malloc(sizeof(xmat));
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 32; j++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0}; v[i] = 1u << j; xorwow_step_v(v);
+        memcpy(a->row[i * 32 + j], v, sizeof v);
+    }
+    for (int s = 0; s < 67; s++) { xmat_square(a, b); xmat* t = a; a = b; b = t; }
+    g_jump[0] = *a;
+    for (int k = 1; k < 32; k++) xmat_square(&g_jump[k - 1], &g_jump[k]);
+    free(a); free(b);
+    g_jump_ready = 1;
+}
+void po_rng_init(uint64_t seed, uint64_t subsequence, uint32_t st[6]) {
+    init_jump_tables();
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    st[5] = 6615241u + t1 + t0;          /* d */
+    st[0] = 123456789u + t0;
+    st[1] = 362436069u ^ t0;
+    st[2] = 521288629u + t1;
+    st[3] = 88675123u ^ t1;
+    st[4] = 5783321u + t0;
+    for (int k = 0; k < 32; k++)
+        if (subsequence & (1ull << k)) { uint32_t o[5]; xmat_apply(&g_jump[k], st, o); memcpy(st, o, sizeof o); }
+    /* offset = 0 at every call site */
+}
+static inline uint32_t xorwow_next(uint32_t st[6]) {
+    xorwow_step_v(st);
+    st[5] += 362437u;
+    return st[4] + st[5];
+}
+static inline float rng_uniform(uint32_t st[6]) {
+    uint32_t x = xorwow_next(st);
+    return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+float po_rng_uniform(uint32_t st[6]) { return rng_uniform(st); }
+
+/* test hook: T^(2^log2n) built by repeated squaring must equal 2^log2n direct steps */
+int po_rng_selftest(int log2n, const uint32_t v_in[5]) {
+    xmat* a = (xmat*)malloc(sizeof(xmat)); xmat* b = (xmat*)malloc(sizeof(xmat));
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 32; j++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0}; v[i] = 1u << j; xorwow_step_v(v);
+        memcpy(a->row[i * 32 + j], v, sizeof v);
+    }
+    for (int s = 0; s < log2n; s++) { xmat_square(a, b); xmat* t = a; a = b; b = t; }
+    uint32_t viaM[5], direct[5];
+    xmat_apply(a, v_in, viaM);
+    memcpy(direct, v_in, sizeof direct);
+    for (uint64_t i = 0; i < (1ull << log2n); i++) xorwow_step_v(direct);
+    free(a); free(b);
+    return memcmp(viaM, direct, sizeof direct) == 0 ? 0 : 1;
+}
+
+void po_sincosf(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }
+float po_powf(float x, float y) { return ptmi_powf(x, y); }
+
+/* ------------------------------------------------------------------------ */
+/* triangle.h:64-96, quad.h:49-132, primitive.h:83-90                        */
+/* ------------------------------------------------------------------------ */
+static inline int tri_intersect(const oprim* p, const ray_t* r, float t_min, float t_max, float* t_out) {
+    const float EPSILON = 1e-8f;
+    v3 edge1 = vsub(p->v[1], p->v[0]);
+    v3 edge2 = vsub(p->v[2], p->v[0]);
+    v3 h = vcross(r->d, edge2);
+    float a = vdot(edge1, h);
+    if (fabsf(a) < EPSILON) return 0;
+    float f = 1.0f / a;
+    v3 s = vsub(r->o, p->v[0]);
+    float u = f * vdot(s, h);
+    if (u < 0.0f || u > 1.0f) return 0;
+    v3 q = vcross(s, edge1);
+    float v = f * vdot(r->d, q);
+    if (v < 0.0f || u + v > 1.0f) return 0;
+    float t = f * vdot(edge2, q);
+    if (t > EPSILON && t >= t_min && t <= t_max) { *t_out = t; return 1; }
+    return 0;
+}
+static inline int quad_half(v3 v00, v3 va, v3 vb, const ray_t* r, float t_min, float* closest_t) {
+    const float EPSILON = 1e-8f;
+    v3 edge1 = vsub(va, v00);
+    v3 edge2 = vsub(vb, v00);
+    v3 h = vcross(r->d, edge2);
+    float a = vdot(edge1, h);
+    if (fabsf(a) > EPSILON) {
+        float f = 1.0f / a;
+        v3 s = vsub(r->o, v00);
+        float u = f * vdot(s, h);
+        if (u >= 0.0f && u <= 1.0f) {
+            v3 q = vcross(s, edge1);
+            float v = f * vdot(r->d, q);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                float t = f * vdot(edge2, q);
+                if (t > EPSILON && t >= t_min && t < *closest_t) { *closest_t = t; return 1; }
+            }
+        }
+    }
+    return 0;
+}
+static inline int quad_intersect(const oprim* p, const ray_t* r, float t_min, float t_max, float* t_out) {
+    float closest_t = t_max; int hit = 0;
+    hit |= quad_half(p->v[0], p->v[1], p->v[2], r, t_min, &closest_t);   /* (v00, v10, v11) */
+    hit |= quad_half(p->v[0], p->v[2], p->v[3], r, t_min, &closest_t);   /* (v00, v11, v01) */
+    if (hit) { *t_out = closest_t; return 1; }
+    return 0;
+}
+static inline int prim_intersect(const oprim* p, const ray_t* r, float t_min, float t_max, float* t_out) {
+    return p->type == PRIM_TRIANGLE ? tri_intersect(p, r, t_min, t_max, t_out) : quad_intersect(p, r, t_min, t_max, t_out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* scene.h:39-129                                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct { uint64_t rays, node_visits, prim_tests, hits; } counters;
+
+static int scene_intersect_bvh(const po_scene* sc, const ray_t* r, float t_min, float t_max,
+                               float* t_hit, int* prim_hit, counters* cn) {   /* scene.h:50-110 */
+    int hit_anything = 0;
+    float closest_t = t_max;
+    int stack[64]; int stack_ptr = 0;
+    stack[stack_ptr++] = 0;
+    float inv_dir[3] = { 1.0f / r->d.e[0], 1.0f / r->d.e[1], 1.0f / r->d.e[2] };
+    while (stack_ptr > 0) {
+        int node_idx = stack[--stack_ptr];
+        const onode* node = &sc->nodes[node_idx];
+        cn->node_visits++;
+        float tmin_box = t_min, tmax_box = closest_t;
+        for (int a = 0; a < 3; a++) {
+            float t0 = (node->bmin.e[a] - r->o.e[a]) * inv_dir[a];
+            float t1 = (node->bmax.e[a] - r->o.e[a]) * inv_dir[a];
+            if (inv_dir[a] < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+            tmin_box = t0 > tmin_box ? t0 : tmin_box;
+            tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        }
+        if (tmax_box < tmin_box) continue;
+        if (node->prim_count > 0) {
+            for (int i = 0; i < node->prim_count; i++) {
+                int prim_idx = sc->indices[node->left_child + i];
+                float t;
+                cn->prim_tests++;
+                if (prim_intersect(&sc->prims[prim_idx], r, t_min, closest_t, &t)) {
+                    if (t < closest_t) { closest_t = t; *prim_hit = prim_idx; hit_anything = 1; }
+                }
+            }
+        } else {
+            if (stack_ptr < 62) { stack[stack_ptr++] = node->right_child; stack[stack_ptr++] = node->left_child; }
+        }
+    }
+    *t_hit = closest_t;
+    return hit_anything;
+}
+static int scene_intersect_linear(const po_scene* sc, const ray_t* r, float t_min, float t_max,
+                                  float* t_hit, int* prim_hit, counters* cn) {   /* scene.h:113-129 */
+    int hit_anything = 0; float si_t = t_max;
+    for (int i = 0; i < sc->n_prims; i++) {
+        float t;
+        cn->prim_tests++;
+        if (prim_intersect(&sc->prims[i], r, t_min, si_t, &t)) {
+            if (t < si_t) { si_t = t; *prim_hit = i; hit_anything = 1; }
+        }
+    }
+    *t_hit = si_t;
+    return hit_anything;
+}
+
+void po_intersect(const po_scene* sc, const float o[3], const float d[3], float t_min, float t_max,
+                  int use_bvh, po_hit* out) {
+    ray_t r; r.o = V(o[0], o[1], o[2]); r.d = V(d[0], d[1], d[2]);   /* direction taken as given */
+    counters cn = {0, 0, 0, 0};
+    float t = 0; int prim = -1;
+    int hit = use_bvh ? scene_intersect_bvh(sc, &r, t_min, t_max, &t, &prim, &cn)
+                      : scene_intersect_linear(sc, &r, t_min, t_max, &t, &prim, &cn);
+    memset(out, 0, sizeof *out);
+    out->hit = hit; out->prim = hit ? prim : -1;
+    out->node_visits = (int)cn.node_visits; out->prim_tests = (int)cn.prim_tests;
+    if (hit) {
+        const oprim* p = &sc->prims[prim];
+        v3 pt = vadd(r.o, vscale(t, r.d));   /* triangle.h:90, quad.h:126 */
+        out->t = t;
+        for (int k = 0; k < 3; k++) { out->p[k] = pt.e[k]; out->n[k] = p->normal.e[k]; out->bsdf[k] = p->bsdf.e[k]; out->Le[k] = p->Le.e[k]; }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* integrator.h:62-85 sampleCosineHemisphere                                  */
+/* ------------------------------------------------------------------------ */
+static v3 sample_cosine_hemisphere_uv(v3 normal, float u, float v) {
+    float r = sqrtf(u);
+    float phi = (float)((double)2.0f * PTMI_PI_D * (double)v);   /* 2.0f * M_PI * v, M_PI double */
+    float sphi, cphi;
+    ptmi_sincosf(phi, &sphi, &cphi);
+    float x = r * cphi;
+    float y = r * sphi;
+    float z = sqrtf(fmaxf(0.0f, 1.0f - u));
+    v3 tangent, bitangent;
+    if (normal.e[2] < -0.9999999f) {
+        tangent = V(0.0f, -1.0f, 0.0f);
+        bitangent = V(-1.0f, 0.0f, 0.0f);
+    } else {
+        float a = 1.0f / (1.0f + normal.e[2]);
+        float b = -normal.e[0] * normal.e[1] * a;
+        tangent = V(1.0f - normal.e[0] * normal.e[0] * a, b, -normal.e[0]);
+        bitangent = V(b, 1.0f - normal.e[1] * normal.e[1] * a, -normal.e[1]);
+    }
+    /* tangent * x + bitangent * y + normal * z */
+    return vunit(vadd(vadd(vscale(x, tangent), vscale(y, bitangent)), vscale(z, normal)));
+}
+void po_sample_cosine_hemisphere(const float n[3], float u, float v, float out[3]) {
+    v3 d = sample_cosine_hemisphere_uv(V(n[0], n[1], n[2]), u, v);
+    for (int k = 0; k < 3; k++) out[k] = d.e[k];
+}
+
+/* ------------------------------------------------------------------------ */
+/* integrator.h:189-268 integrator(), BSDF mode                               */
+/* ------------------------------------------------------------------------ */
+static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint32_t rng[6], counters* cn) {
+    v3 throughput = V(1.0f, 1.0f, 1.0f);
+    ray_t r = ray;
+    for (int depth = 0; depth < max_depth; depth++) {
+        float t; int prim = -1;
+        cn->rays++;
+        if (!scene_intersect_bvh(sc, &r, 1e-4f, FLT_MAX, &t, &prim, cn)) break;   /* :198-201 */
+        cn->hits++;
+        const oprim* p = &sc->prims[prim];
+        v3 si_p = vadd(r.o, vscale(t, r.d));
+        *L = vadd(*L, vmul(throughput, p->Le));                                  /* :204 */
+        if (depth > 2) {                                                         /* :207-212 */
+            float max_throughput = fmaxf(throughput.e[0], fmaxf(throughput.e[1], throughput.e[2]));
+            float rr_prob = fminf(max_throughput, 0.95f);
+            if (rng_uniform(rng) > rr_prob) break;
+            float k = recip_via_double(rr_prob);                                 /* throughput /= rr_prob */
+            throughput = V(throughput.e[0] * k, throughput.e[1] * k, throughput.e[2] * k);
+        }
+        throughput = vmul(throughput, p->bsdf);                                  /* :215 */
+        if (vlen(throughput) < 1e-5f) break;                                     /* :218 */
+        v3 normal = p->normal;
+        v3 shading_normal = vdot(r.d, normal) < 0 ? normal : vneg(normal);       /* :221-222 */
+        float u = rng_uniform(rng);                                              /* :63-64: u then v */
+        float v = rng_uniform(rng);
+        v3 next_dir = sample_cosine_hemisphere_uv(shading_normal, u, v);         /* :230 */
+        r = make_ray(vadd(si_p, vscale(1e-4f, shading_normal)), next_dir);       /* :266 */
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* integrator.h:371-408 render kernel                                        */
+/* ------------------------------------------------------------------------ */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+int po_render(const po_scene* sc, const po_camera* cam, int width, int height, int spp, int max_depth,
+              uint64_t seed_base, int reset_rng, uint32_t* rng_state,
+              int y0, int y1, int n_threads,
+              unsigned char* out_rgb8, float* out_radiance, po_stats* stats) {
+    if (!sc || width <= 0 || height <= 0 || spp <= 0 || y0 < 0 || y1 > height || y0 > y1) return -1;
+    init_jump_tables();
+    po_camera_frame cf; po_camera_frame_setup(cam, width, height, &cf);
+    counters total = {0, 0, 0, 0};
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_num_procs();
+#else
+    n_threads = 1;
+#endif
+    /* render_init (integrator.h:274-280) is a separate, untimed pass, as in the
+     * reference where it runs once per allocateBuffers(). */
+    uint32_t* own_state = NULL;
+    if (!rng_state) { own_state = (uint32_t*)malloc(sizeof(uint32_t) * 6 * (size_t)width * (size_t)(y1 - y0)); reset_rng = 1; }
+    if (reset_rng) {
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < width; x++) {
+                int pixel_index = y * width + x;
+                uint32_t* st = rng_state ? &rng_state[(size_t)pixel_index * 6]
+                                         : &own_state[((size_t)(y - y0) * (size_t)width + (size_t)x) * 6];
+                po_rng_init(seed_base + (uint64_t)pixel_index, (uint64_t)pixel_index, st);   /* :279 */
+            }
+    }
+    double t_start = now_s();
+    uint64_t c_rays = 0, c_nodes = 0, c_tests = 0, c_hits = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : c_rays, c_nodes, c_tests, c_hits)
+    for (int y = y0; y < y1; y++) {
+        counters cn = {0, 0, 0, 0};
+        for (int x = 0; x < width; x++) {
+            int pixel_index = y * width + x;
+            uint32_t* rng = rng_state ? &rng_state[(size_t)pixel_index * 6]
+                                      : &own_state[((size_t)(y - y0) * (size_t)width + (size_t)x) * 6];
+            v3 color = V(0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < spp; s++) {
+                float u = ((float)x + rng_uniform(rng)) / (float)width;    /* :384 */
+                float v = ((float)y + rng_uniform(rng)) / (float)height;   /* :385 */
+                ray_t ray = camera_get_ray(&cf, u, v);
+                v3 sample_color = V(0.0f, 0.0f, 0.0f);
+                integrator(sc, ray, &sample_color, max_depth, rng, &cn);
+                color = vadd(color, sample_color);
+            }
+            {   /* color /= float(spp) : vector.h:90-94 */
+                float k = recip_via_double((float)spp);
+                color = V(color.e[0] * k, color.e[1] * k, color.e[2] * k);
+            }
+            if (out_radiance) for (int c = 0; c < 3; c++) out_radiance[(size_t)pixel_index * 3 + c] = color.e[c];
+            if (out_rgb8) {
+                v3 tm = vdivv(color, vadd(color, V(1.0f, 1.0f, 1.0f)));   /* :396 */
+                const float gamma = 1.0f / 2.2f;
+                for (int c = 0; c < 3; c++) {
+                    float g = ptmi_powf(tm.e[c], gamma);
+                    out_rgb8[(size_t)pixel_index * 3 + c] = (unsigned char)(255.99f * fminf(g, 1.0f));
+                }
+            }
+        }
+        c_rays += cn.rays; c_nodes += cn.node_visits; c_tests += cn.prim_tests; c_hits += cn.hits;
+    }
+    total.rays = c_rays; total.node_visits = c_nodes; total.prim_tests = c_tests; total.hits = c_hits;
+    double t_end = now_s();
+    free(own_state);
+    if (stats) {
+        stats->seconds = t_end - t_start;
+        stats->samples = (uint64_t)width * (uint64_t)(y1 - y0) * (uint64_t)spp;
+        stats->rays = total.rays; stats->node_visits = total.node_visits;
+        stats->prim_tests = total.prim_tests; stats->hits = total.hits;
+    }
+    return 0;
+}

@@ -1,0 +1,83 @@
+/* ptmi_oracle.h — C interface of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libptmi.so) never links, loads or calls it.
+ */
+#ifndef PTMI_ORACLE_H
+#define PTMI_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct po_scene po_scene;
+
+typedef struct {
+    float origin[3], lookat[3], vup[3];
+    float vfov_deg;
+    float yaw_deg, pitch_deg;
+    int orbit;            /* 1 = renderFrame() behaviour: updateCameraOrbit() before use */
+} po_camera;
+
+/* derived camera exactly as the reference's Sensor holds it */
+typedef struct {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3];
+} po_camera_frame;
+
+typedef struct {
+    double seconds;
+    uint64_t samples, rays, node_visits, prim_tests, hits;
+} po_stats;
+
+typedef struct {
+    int hit;        /* 0/1 */
+    int prim;       /* index into the scene's primitive list (load order) */
+    float t, p[3], n[3], bsdf[3], Le[3];
+    int node_visits, prim_tests;
+} po_hit;
+
+/* scene ----------------------------------------------------------------- */
+po_scene* po_scene_load(const char* path, int subdivision_count, int convert_quads);
+/* type[i]: 0 triangle (v: 3 verts), 1 quad (v: 4 verts); verts: n*4*3 floats
+ * (4th vertex ignored for triangles); normal/bsdf/Le: n*3 floats each. */
+po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
+                               const float* normal, const float* bsdf, const float* Le);
+void po_scene_free(po_scene*);
+int po_scene_num_prims(const po_scene*);
+int po_scene_num_nodes(const po_scene*);
+/* out arrays sized by the two counts above */
+void po_scene_get_prims(const po_scene*, int* type, float* verts, float* normal, float* bsdf, float* Le);
+void po_scene_get_bvh(const po_scene*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
+
+/* camera, rng, numerics -------------------------------------------------- */
+void po_camera_frame_setup(const po_camera*, int width, int height, po_camera_frame* out);
+void po_camera_ray(const po_camera_frame*, float u, float v, float o[3], float d[3]);
+void po_rng_init(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
+float po_rng_uniform(uint32_t state[6]);
+int po_rng_selftest(int log2n, const uint32_t v_in[5]);
+void po_sincosf(float x, float* s, float* c);
+float po_powf(float x, float y);
+void po_sample_cosine_hemisphere(const float n[3], float u, float v, float out[3]);
+
+/* intersection ------------------------------------------------------------ */
+void po_intersect(const po_scene*, const float o[3], const float d[3], float t_min, float t_max,
+                  int use_bvh, po_hit* out);
+
+/* render -------------------------------------------------------------------
+ * Renders rows [y0, y1) of a width x height frame.  out_rgb8 / out_radiance
+ * are FULL-frame buffers (width*height*3), row 0 = bottom, only the requested
+ * rows are written.  rng_state: optional width*height*6 uint32 persistent
+ * state; if NULL or reset_rng != 0 the state is (re)initialised as render_init
+ * does.  n_threads <= 0: all cores. */
+int po_render(const po_scene*, const po_camera*, int width, int height, int spp, int max_depth,
+              uint64_t seed_base, int reset_rng, uint32_t* rng_state,
+              int y0, int y1, int n_threads,
+              unsigned char* out_rgb8, float* out_radiance, po_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
