@@ -1,0 +1,364 @@
+// c_api.cpp — the C ABI of libptmi.so (include/ptmi.h) over the host-side state objects.
+#include "../../include/ptmi.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "../host/application_state.h"
+
+using namespace ptmi;
+
+struct ptmi_ctx { ApplicationState app; explicit ptmi_ctx(int dev) : app(dev) {} };
+struct ptmi_host_scene { SceneState scene; };
+
+namespace {
+thread_local std::string g_last_error;
+
+template <class Fn>
+int guarded(Fn&& fn) {
+    try { fn(); return PTMI_OK; }
+    catch (const HipError& e) {
+        g_last_error = e.what();
+        if (e.code == hipErrorNoDevice || e.code == hipErrorInvalidDevice) return PTMI_E_NO_DEVICE;
+        if (e.code == hipErrorOutOfMemory) return PTMI_E_NOMEM;
+        return PTMI_E_HIP;
+    }
+    catch (const IoError& e) { g_last_error = e.what(); return PTMI_E_IO; }
+    catch (const ArgError& e) { g_last_error = e.what(); return PTMI_E_INVALID; }
+    catch (const std::bad_alloc&) { g_last_error = "host allocation failed"; return PTMI_E_NOMEM; }
+    catch (const std::exception& e) { g_last_error = e.what(); return PTMI_E_INVALID; }
+    catch (...) { g_last_error = "unknown error"; return PTMI_E_INVALID; }
+}
+void need(bool ok, const char* what) { if (!ok) throw ArgError(what); }
+f3 v3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+#define PTMI_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) throw HipError(e_, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    explicit DevBuf(size_t n) { p = (T*)hipMallocSafe(n * sizeof(T), "debug buffer"); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void upload(const T* h, size_t n) { PTMI_HIP(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice)); }
+    void download(T* h, size_t n) { PTMI_HIP(hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost)); }
+};
+}  // namespace
+
+static std::vector<Primitive> prims_from_arrays(int n, const int* type, const float* verts, const float* normal,
+                                                const float* bsdf, const float* Le);
+
+extern "C" {
+
+const char* ptmi_last_error(void) { return g_last_error.c_str(); }
+
+void ptmi_default_camera(ptmi_camera* c) {
+    const AppConfig d;
+    c->origin[0] = d.camera_origin.x; c->origin[1] = d.camera_origin.y; c->origin[2] = d.camera_origin.z;
+    c->lookat[0] = d.look_at.x; c->lookat[1] = d.look_at.y; c->lookat[2] = d.look_at.z;
+    c->vup[0] = d.up.x; c->vup[1] = d.up.y; c->vup[2] = d.up.z;
+    c->vfov_deg = d.fov; c->yaw_deg = 90.0f; c->pitch_deg = 0.0f; c->orbit = 1;
+}
+void ptmi_default_config(ptmi_config* c) {
+    const AppConfig d;
+    c->spp = d.spp; c->max_depth = d.max_depth; c->sampling_mode = (int)d.sampling_mode; c->seed_base = d.seed_base;
+    c->segments_per_launch = 0; c->collect_stats = 0;
+}
+void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
+
+int ptmi_ctx_create(int device_id, ptmi_ctx** out) {
+    return guarded([&] { need(out != nullptr, "out is NULL"); *out = nullptr; *out = new ptmi_ctx(device_id); });
+}
+void ptmi_ctx_destroy(ptmi_ctx* c) { delete c; }
+
+int ptmi_load_scene(ptmi_ctx* c, const char* filename, int subdivision_count, int convert_quads) {
+    return guarded([&] {
+        need(c && filename, "ctx/filename is NULL");
+        need(subdivision_count >= 0 && subdivision_count <= 10, "subdivision_count must be in [0, 10]");   // UI range, ui_windows.h:213
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.config.convert_quads_to_triangles = convert_quads != 0;
+        c->app.scene.loadScene(filename, subdivision_count, convert_quads != 0);
+    });
+}
+
+int ptmi_load_scene_arrays(ptmi_ctx* c, int n, const int* type, const float* verts, const float* normal,
+                           const float* bsdf, const float* Le) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.scene.loadSceneArrays(prims_from_arrays(n, type, verts, normal, bsdf, Le));
+    });
+}
+
+static void scene_info(const SceneState& s, int* n_prims, int* n_tris, int* n_quads, int* n_bvh_nodes, int* bvh_depth) {
+    if (n_prims) *n_prims = (int)s.h_primitives.size();
+    if (n_tris) *n_tris = s.num_tris;
+    if (n_quads) *n_quads = s.num_quads;
+    if (n_bvh_nodes) *n_bvh_nodes = (int)s.bvh_nodes.size();
+    if (bvh_depth) *bvh_depth = s.bvh_depth;
+}
+static void scene_get_prims(const SceneState& sc, int* type, float* verts, float* normal, float* bsdf, float* Le) {
+    {
+        const auto& ps = sc.h_primitives;
+        for (size_t i = 0; i < ps.size(); i++) {
+            const Primitive& p = ps[i];
+            if (type) type[i] = (int)p.type;
+            if (verts) for (int k = 0; k < 4; k++) { verts[(i * 4 + k) * 3] = p.v[k].x; verts[(i * 4 + k) * 3 + 1] = p.v[k].y; verts[(i * 4 + k) * 3 + 2] = p.v[k].z; }
+            if (normal) { normal[i * 3] = p.normal.x; normal[i * 3 + 1] = p.normal.y; normal[i * 3 + 2] = p.normal.z; }
+            if (bsdf) { bsdf[i * 3] = p.bsdf.x; bsdf[i * 3 + 1] = p.bsdf.y; bsdf[i * 3 + 2] = p.bsdf.z; }
+            if (Le) { Le[i * 3] = p.Le.x; Le[i * 3 + 1] = p.Le.y; Le[i * 3 + 2] = p.Le.z; }
+        }
+    }
+}
+static void scene_get_bvh(const SceneState& s, float* bmin, float* bmax, int* left, int* right, int* count, int* indices) {
+    {
+        for (size_t i = 0; i < s.bvh_nodes.size(); i++) {
+            const BVHNode& n = s.bvh_nodes[i];
+            if (bmin) { bmin[i * 3] = n.bbox.min.x; bmin[i * 3 + 1] = n.bbox.min.y; bmin[i * 3 + 2] = n.bbox.min.z; }
+            if (bmax) { bmax[i * 3] = n.bbox.max.x; bmax[i * 3 + 1] = n.bbox.max.y; bmax[i * 3 + 2] = n.bbox.max.z; }
+            if (left) left[i] = n.left_child;
+            if (right) right[i] = n.right_child;
+            if (count) count[i] = n.prim_count;
+        }
+        if (indices) std::memcpy(indices, s.bvh_indices.data(), s.bvh_indices.size() * sizeof(int));
+    }
+}
+static std::vector<Primitive> prims_from_arrays(int n, const int* type, const float* verts, const float* normal,
+                                                const float* bsdf, const float* Le) {
+    need(type && verts && normal && bsdf && Le, "NULL argument");
+    need(n > 0, "n must be positive");
+    std::vector<Primitive> prims((size_t)n);
+    for (int i = 0; i < n; i++) {
+        Primitive& p = prims[i];
+        need(type[i] == 0 || type[i] == 1, "type must be 0 (triangle) or 1 (quad)");
+        p.type = type[i] ? PRIM_QUAD : PRIM_TRIANGLE;
+        for (int k = 0; k < 4; k++) p.v[k] = v3(verts + ((size_t)i * 4 + k) * 3);
+        if (p.type == PRIM_TRIANGLE) p.v[3] = mk3(0, 0, 0);
+        p.normal = v3(normal + (size_t)i * 3); p.bsdf = v3(bsdf + (size_t)i * 3); p.Le = v3(Le + (size_t)i * 3);
+    }
+    return prims;
+}
+
+int ptmi_scene_info(const ptmi_ctx* c, int* n_prims, int* n_tris, int* n_quads, int* n_bvh_nodes, int* bvh_depth) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); scene_info(c->app.scene, n_prims, n_tris, n_quads, n_bvh_nodes, bvh_depth); });
+}
+int ptmi_scene_get_prims(const ptmi_ctx* c, int* type, float* verts, float* normal, float* bsdf, float* Le) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); scene_get_prims(c->app.scene, type, verts, normal, bsdf, Le); });
+}
+int ptmi_scene_get_bvh(const ptmi_ctx* c, float* bmin, float* bmax, int* left, int* right, int* count, int* indices) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); scene_get_bvh(c->app.scene, bmin, bmax, left, right, count, indices); });
+}
+
+int ptmi_host_scene_load(const char* filename, int subdivision_count, int convert_quads, ptmi_host_scene** out) {
+    return guarded([&] {
+        need(filename && out, "NULL argument");
+        need(subdivision_count >= 0 && subdivision_count <= 10, "subdivision_count must be in [0, 10]");
+        *out = nullptr;
+        std::unique_ptr<ptmi_host_scene> hs(new ptmi_host_scene);
+        hs->scene.loadSceneHost(filename, subdivision_count, convert_quads != 0);
+        *out = hs.release();
+    });
+}
+int ptmi_host_scene_from_arrays(int n, const int* type, const float* verts, const float* normal,
+                                const float* bsdf, const float* Le, ptmi_host_scene** out) {
+    return guarded([&] {
+        need(out != nullptr, "out is NULL");
+        *out = nullptr;
+        std::unique_ptr<ptmi_host_scene> hs(new ptmi_host_scene);
+        hs->scene.loadSceneArraysHost(prims_from_arrays(n, type, verts, normal, bsdf, Le));
+        *out = hs.release();
+    });
+}
+void ptmi_host_scene_free(ptmi_host_scene* s) { delete s; }
+int ptmi_host_scene_info(const ptmi_host_scene* s, int* n_prims, int* n_tris, int* n_quads, int* n_bvh_nodes, int* bvh_depth) {
+    return guarded([&] { need(s != nullptr, "scene is NULL"); scene_info(s->scene, n_prims, n_tris, n_quads, n_bvh_nodes, bvh_depth); });
+}
+int ptmi_host_scene_get_prims(const ptmi_host_scene* s, int* type, float* verts, float* normal, float* bsdf, float* Le) {
+    return guarded([&] { need(s != nullptr, "scene is NULL"); scene_get_prims(s->scene, type, verts, normal, bsdf, Le); });
+}
+int ptmi_host_scene_get_bvh(const ptmi_host_scene* s, float* bmin, float* bmax, int* left, int* right, int* count, int* indices) {
+    return guarded([&] { need(s != nullptr, "scene is NULL"); scene_get_bvh(s->scene, bmin, bmax, left, right, count, indices); });
+}
+int ptmi_host_camera_frame(const ptmi_camera* cam, int width, int height, float* out12) {
+    return guarded([&] {
+        need(cam && out12, "NULL argument");
+        need(width > 0 && height > 0, "width and height must be positive");
+        Sensor s(v3(cam->origin), v3(cam->lookat), v3(cam->vup), cam->vfov_deg, 1.0f);   // application.h:107-113
+        s.yaw = cam->yaw_deg; s.pitch = cam->pitch_deg;
+        s.image_width = width; s.image_height = height;
+        s.aspect = (float)width / (float)height;                                        // application_state.h:108
+        s.updateCamera();
+        if (cam->orbit) s.updateCameraOrbit();                                          // application.h:161
+        const CameraFrame f = s.frame();
+        const f3 v[4] = {f.origin, f.lower_left_corner, f.horizontal, f.vertical};
+        for (int i = 0; i < 4; i++) { out12[3 * i] = v[i].x; out12[3 * i + 1] = v[i].y; out12[3 * i + 2] = v[i].z; }
+    });
+}
+int ptmi_host_local_row_map(int height, const ptmi_tiling* t, int* n_rows, int* rows_out) {
+    return guarded([&] {
+        need(t && n_rows, "NULL argument");
+        need(height > 0 && t->n_ranks >= 1 && t->rank >= 0 && t->rank < t->n_ranks && t->row_block >= 1, "bad tiling");
+        TileMap tm; tm.height = height; tm.n_ranks = t->n_ranks; tm.rank = t->rank; tm.row_block = t->row_block;
+        const std::vector<int> rows = localRowMap(tm);
+        *n_rows = (int)rows.size();
+        if (rows_out) std::memcpy(rows_out, rows.data(), rows.size() * sizeof(int));
+    });
+}
+
+int ptmi_update_resolution(ptmi_ctx* c, int width, int height, const ptmi_tiling* tiling) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        TileMap tm;
+        if (tiling) { tm.n_ranks = tiling->n_ranks; tm.rank = tiling->rank; tm.row_block = tiling->row_block; }
+        c->app.render.seed_base = c->app.config.seed_base;
+        c->app.render.updateResolution(width, height, tiling ? &tm : nullptr);
+    });
+}
+
+int ptmi_set_camera(ptmi_ctx* c, const ptmi_camera* cam) {
+    return guarded([&] {
+        need(c && cam, "NULL argument");
+        AppConfig& cfg = c->app.config;
+        cfg.camera_origin = v3(cam->origin); cfg.look_at = v3(cam->lookat); cfg.up = v3(cam->vup);
+        cfg.fov = cam->vfov_deg; cfg.orbit = cam->orbit != 0;
+        Sensor& s = c->app.render.h_camera;
+        const int w = s.image_width, h = s.image_height; const float aspect = s.aspect;
+        s = Sensor(cfg.camera_origin, cfg.look_at, cfg.up, cfg.fov, 1.0f);    // application.h:107-113
+        s.yaw = cam->yaw_deg; s.pitch = cam->pitch_deg;
+        s.image_width = w; s.image_height = h;
+        if (w > 0) { s.aspect = aspect; s.updateCamera(); }
+    });
+}
+
+int ptmi_set_config(ptmi_ctx* c, const ptmi_config* cfg) {
+    return guarded([&] {
+        need(c && cfg, "NULL argument");
+        need(cfg->spp >= 1 && cfg->spp < (1 << 24), "spp must be in [1, 2^24)");
+        need(cfg->max_depth >= 1 && cfg->max_depth <= 255, "max_depth must be in [1, 255]");
+        need(cfg->sampling_mode == 0, "only sampling_mode 0 (SAMPLING_BSDF) is implemented");
+        need(cfg->segments_per_launch >= 0, "segments_per_launch must be >= 0");
+        AppConfig& a = c->app.config;
+        a.spp = cfg->spp; a.max_depth = cfg->max_depth; a.sampling_mode = SamplingMode::SAMPLING_BSDF;
+        a.seed_base = cfg->seed_base; a.segments_per_launch = cfg->segments_per_launch; a.collect_stats = cfg->collect_stats != 0;
+    });
+}
+
+int ptmi_get_camera_frame(const ptmi_ctx* c, float* out12) {
+    return guarded([&] {
+        need(c && out12, "NULL argument");
+        Sensor s = c->app.render.h_camera;                 // copy: what renderFrame() would derive
+        if (c->app.config.orbit) s.updateCameraOrbit(); else s.updateCamera();
+        const CameraFrame f = s.frame();
+        const f3 v[4] = {f.origin, f.lower_left_corner, f.horizontal, f.vertical};
+        for (int i = 0; i < 4; i++) { out12[3 * i] = v[i].x; out12[3 * i + 1] = v[i].y; out12[3 * i + 2] = v[i].z; }
+    });
+}
+
+int ptmi_local_rows(const ptmi_ctx* c, int* n_rows) {
+    return guarded([&] { need(c && n_rows, "NULL argument"); *n_rows = c->app.render.tile.local_rows; });
+}
+int ptmi_local_row_map(const ptmi_ctx* c, int* rows_out) {
+    return guarded([&] {
+        need(c && rows_out, "NULL argument");
+        const std::vector<int> rows = localRowMap(c->app.render.tile);
+        std::memcpy(rows_out, rows.data(), rows.size() * sizeof(int));
+    });
+}
+
+int ptmi_render_frame(ptmi_ctx* c, ptmi_stats* stats) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        FrameStats fs;
+        renderFrame(c->app, stats ? &fs : nullptr);
+        if (stats) {
+            stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches;
+            stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
+            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits;
+        }
+    });
+}
+
+int ptmi_device_image(const ptmi_ctx* c, void** d_rgb8, void** d_radiance) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(c->app.render.d_image != nullptr, "buffers not allocated");
+        if (d_rgb8) *d_rgb8 = c->app.render.d_image;
+        if (d_radiance) *d_radiance = c->app.render.d_radiance;
+    });
+}
+
+int ptmi_read_image(const ptmi_ctx* c, unsigned char* rgb8, float* radiance) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        const RenderState& r = c->app.render;
+        need(r.d_image != nullptr, "buffers not allocated");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        if (rgb8) PTMI_HIP(hipMemcpy(rgb8, r.d_image, r.n_local * 3, hipMemcpyDeviceToHost));                       // application.h:211
+        if (radiance) PTMI_HIP(hipMemcpy(radiance, r.d_radiance, r.n_local * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int ptmi_copy_image_device(const ptmi_ctx* c, void* d_rgb8_dst, void* d_radiance_dst) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        const RenderState& r = c->app.render;
+        need(r.d_image != nullptr, "buffers not allocated");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        if (d_rgb8_dst) PTMI_HIP(hipMemcpyAsync(d_rgb8_dst, r.d_image, r.n_local * 3, hipMemcpyDeviceToDevice, r.stream));
+        if (d_radiance_dst) PTMI_HIP(hipMemcpyAsync(d_radiance_dst, r.d_radiance, r.n_local * 3 * sizeof(float), hipMemcpyDeviceToDevice, r.stream));
+        PTMI_HIP(hipStreamSynchronize(r.stream));
+    });
+}
+
+int ptmi_debug_intersect(ptmi_ctx* c, int n, const float* o, const float* d, float t_min, float t_max,
+                         int* hit, int* prim, float* t, float* p, float* nrm) {
+    return guarded([&] {
+        need(c && o && d && hit && prim && t && p && nrm, "NULL argument");
+        need(c->app.scene.d_nodes != nullptr, "no scene loaded");
+        need(n > 0, "n must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        DevBuf<float> d_o(3 * (size_t)n), d_d(3 * (size_t)n), d_t(n), d_p(3 * (size_t)n), d_n(3 * (size_t)n);
+        DevBuf<int> d_hit(n), d_prim(n);
+        d_o.upload(o, 3 * (size_t)n); d_d.upload(d, 3 * (size_t)n);
+        launch_debug_intersect(c->app.scene.d_scene, n, d_o.p, d_d.p, t_min, t_max, d_hit.p, d_prim.p, d_t.p, d_p.p, d_n.p, c->app.render.stream);
+        PTMI_HIP(hipGetLastError());
+        PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
+        d_hit.download(hit, n); d_prim.download(prim, n); d_t.download(t, n); d_p.download(p, 3 * (size_t)n); d_n.download(nrm, 3 * (size_t)n);
+    });
+}
+
+int ptmi_debug_rng(ptmi_ctx* c, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out) {
+    return guarded([&] {
+        need(c && pixels && out, "NULL argument");
+        need(n_pixels > 0 && count > 0, "n_pixels and count must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        DevBuf<int> d_pix(n_pixels); DevBuf<float> d_out((size_t)n_pixels * count);
+        d_pix.upload(pixels, n_pixels);
+        launch_debug_rng(c->app.render.d_jump, seed_base, n_pixels, d_pix.p, count, d_out.p, c->app.render.stream);
+        PTMI_HIP(hipGetLastError());
+        PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
+        d_out.download(out, (size_t)n_pixels * count);
+    });
+}
+
+int ptmi_debug_cosine_sample(ptmi_ctx* c, int n, const float* normals, const float* u, const float* v, float* out_dirs) {
+    return guarded([&] {
+        need(c && normals && u && v && out_dirs, "NULL argument");
+        need(n > 0, "n must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        DevBuf<float> d_n(3 * (size_t)n), d_u(n), d_v(n), d_o(3 * (size_t)n);
+        d_n.upload(normals, 3 * (size_t)n); d_u.upload(u, n); d_v.upload(v, n);
+        launch_debug_cosine(n, d_n.p, d_u.p, d_v.p, d_o.p, c->app.render.stream);
+        PTMI_HIP(hipGetLastError());
+        PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
+        d_o.download(out_dirs, 3 * (size_t)n);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// device_scene.h — HBM/LDS data layout of the render path and the kernel launch API.
+//
+// Everything the kernels touch is an array of 16-byte vectors so that a wave
+// reads/writes 1 KiB per instruction (global_load_dwordx4, ds_read_b128).
+//
+// SCENE (read-only, replicated on every GPU; staged into LDS when it fits)
+//   nodes[2*i+0] = (bbox.min.xyz, bits(left))      left : inner -> left child, leaf -> first primitive slot
+//   nodes[2*i+1] = (bbox.max.xyz, bits(right))     right: inner -> right child (>0), leaf -> -prim_count (<0)
+//   prims[S*k+0] = (v0.xyz, bits(type))            k = LEAF-ORDER slot (reference's bvh_indices applied on the host,
+//   prims[S*k+1] = (v1-v0 | v10-v00, 0)              so a leaf's primitives are contiguous); S = 3 for triangle-only
+//   prims[S*k+2] = (v2-v0 | v11-v00, 0)              scenes, 4 when quads are present.  Edges are precomputed with the
+//   prims[S*k+3] = (      - | v01-v00, 0)            same float subtraction the reference performs per test.
+//   mats[3*k+0]  = (normal.xyz, bits(load-order primitive index))
+//   mats[3*k+1]  = (Kd.xyz, 0)
+//   mats[3*k+2]  = (Ke.xyz, 0)
+//
+// PATH STATE (read+written once per launch per active pixel; slot = local pixel)
+//   A[slot] = (ray.o.xyz, throughput.x)
+//   B[slot] = (ray.d.xyz, throughput.y)
+//   C[slot] = (L_sample.xyz, throughput.z)         L_sample = radiance of the sample in flight (integrator.h:204)
+//   D[slot] = (color.xyz, bits(sample_idx << 8 | depth))   color = sum of finished samples (integrator.h:390)
+//   E[slot] = xorwow v[0..3]                       RNG stream of the pixel: strictly sequential, which is why a
+//   F[slot] = (xorwow v[4], weyl d)                pixel has exactly one path in flight
+//   = 88 B per pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_vec.h"
+
+namespace ptmi {
+
+struct DeviceScene {
+    const float4* nodes = nullptr;
+    const float4* prims = nullptr;
+    const float4* mats = nullptr;
+    int n_nodes = 0, n_prims = 0;
+    int prim_stride = 3;      // float4 per primitive
+    int has_quads = 0;
+    int stack_entries = 1;    // min(bvh depth + 1, 64)
+    int lds_resident = 0;     // 1: nodes+prims+mats are staged into LDS by every workgroup
+};
+
+struct PathState {
+    float4* A = nullptr; float4* B = nullptr; float4* C = nullptr; float4* D = nullptr;
+    uint4* E = nullptr; uint2* F = nullptr;
+};
+
+struct TileMap {              // local row -> global row (ptmi.h: ptmi_tiling)
+    int width = 0, height = 0;
+    int n_ranks = 1, rank = 0, row_block = 8;
+    int local_rows = 0;
+};
+
+struct FrameParams {
+    float cam_origin[3], cam_llc[3], cam_hor[3], cam_ver[3];
+    int spp, max_depth;
+};
+
+struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits; };
+
+constexpr int kBlock = 256;
+constexpr int kXorwowJumpWords = 32 * 160 * 5;   // 32 matrices T^(2^67 * 2^k), 160 rows of 5 words
+
+// ---- launchers (kernels.hip) ------------------------------------------------
+// render_init (integrator.h:274-280): seeds every local pixel's stream and clears its state.
+void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* d_jump, uint64_t seed_base, hipStream_t s);
+// First camera ray of the frame for every local pixel (sample 0 of the spp loop, integrator.h:383-387).
+void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParams& fp, hipStream_t s);
+// The hot kernel: advances every queued path by up to `segments` ray segments, regenerating camera rays when a
+// sample ends; appends still-unfinished pixels to queue_out (wave ballot + prefix popcount, one atomic per wave).
+// queue_in == nullptr means "all local pixels" (identity queue); n_in is then the pixel count.
+void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
+                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
+                   StatCounters* stats /* nullptr: counters compiled out */, hipStream_t s);
+// mean, Reinhard, gamma, 8-bit (integrator.h:393-407) + float radiance.
+void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s);
+
+size_t bounce_lds_bytes(const DeviceScene& sc);
+
+// test hooks
+void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
+                            int* hit, int* prim, float* t, float* p, float* nrm, hipStream_t s);
+void launch_debug_rng(const uint32_t* d_jump, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out, hipStream_t s);
+void launch_debug_cosine(int n, const float* normals, const float* u, const float* v, float* out, hipStream_t s);
+
+}  // namespace ptmi

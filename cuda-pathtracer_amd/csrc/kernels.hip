@@ -1,0 +1,528 @@
+// kernels.hip — gfx950 kernels of the render path.
+//
+// Compile with -ffp-contract=off: results must be bit-identical to the strict-IEEE
+// evaluation of the reference's expressions (see include/ptmi_math.h, pt_vec.h).
+//
+// Kernels
+//   ptmi_render_init   render_init (integrator.h:274-280): XORWOW seeding + 2^67*pixel skip-ahead
+//   ptmi_frame_begin   sample 0's camera ray for every pixel (integrator.h:383-387)
+//   ptmi_bounce        THE hot kernel: intersect (scene.h:50-110, triangle.h:64-96, quad.h:49-132) +
+//                      integrator() body (integrator.h:189-268) + regeneration + queue compaction
+//   ptmi_resolve       integrator.h:393-407
+#include "device_scene.h"
+
+#include <float.h>
+
+#include "../../include/ptmi_math.h"
+
+namespace ptmi {
+
+// ---------------------------------------------------------------------------------------------
+// RNG: cuRAND XORWOW restated (third-party algorithm; see oracle/ptmi_oracle.c header for status)
+// ---------------------------------------------------------------------------------------------
+struct Rng { uint32_t v0, v1, v2, v3, v4, d; };
+
+__device__ __forceinline__ uint32_t rng_next(Rng& r) {
+    const uint32_t t = r.v0 ^ (r.v0 >> 2);
+    r.v0 = r.v1; r.v1 = r.v2; r.v2 = r.v3; r.v3 = r.v4;
+    r.v4 = (r.v4 ^ (r.v4 << 4)) ^ (t ^ (t << 1));
+    r.d += 362437u;
+    return r.v4 + r.d;
+}
+// curand_uniform: x * 2^-32 + 2^-33, in (0, 1]
+__device__ __forceinline__ float rng_uniform(Rng& r) {
+    const uint32_t x = rng_next(r);
+    return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+__device__ __forceinline__ int global_pixel(const TileMap& tm, int slot, int& x, int& y) {
+    const int lr = slot / tm.width;
+    x = slot - lr * tm.width;
+    y = ((lr / tm.row_block) * tm.n_ranks + tm.rank) * tm.row_block + (lr % tm.row_block);
+    return y * tm.width + x;
+}
+
+// One 160x160 GF(2) matrix at a time is staged in LDS (3200 B); rows are read as wave-wide broadcasts.
+__global__ __launch_bounds__(kBlock) void ptmi_render_init(TileMap tm, PathState st, const uint32_t* __restrict__ jump,
+                                                           unsigned long long seed_base) {
+    __shared__ uint32_t M[160 * 5];
+    const int n = tm.local_rows * tm.width;
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = slot < n;
+    int x = 0, y = 0;
+    const unsigned int pix = live ? (unsigned int)global_pixel(tm, slot, x, y) : 0u;
+    const unsigned long long seed = seed_base + (unsigned long long)pix;
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    const uint32_t d = 6615241u + t1 + t0;
+
+    for (int k = 0; k < 32; k++) {
+        const bool mine = live && ((pix >> k) & 1u);
+        if (!__syncthreads_or(mine ? 1 : 0)) continue;     // block-uniform: nobody needs T^(2^67 * 2^k)
+        for (int i = threadIdx.x; i < 160 * 5; i += kBlock) M[i] = jump[k * 160 * 5 + i];
+        __syncthreads();
+        if (mine) {
+            uint32_t r[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int w = 0; w < 5; w++) {
+                const uint32_t word = v[w];
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t m = 0u - ((word >> b) & 1u);
+                    const uint32_t* row = &M[(w * 32 + b) * 5];
+                    r[0] ^= row[0] & m; r[1] ^= row[1] & m; r[2] ^= row[2] & m; r[3] ^= row[3] & m; r[4] ^= row[4] & m;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 5; w++) v[w] = r[w];
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    st.E[slot] = make_uint4(v[0], v[1], v[2], v[3]);
+    st.F[slot] = make_uint2(v[4], d);
+    st.A[slot] = make_float4(0, 0, 0, 1.0f);
+    st.B[slot] = make_float4(0, 0, 1.0f, 1.0f);
+    st.C[slot] = make_float4(0, 0, 0, 1.0f);
+    st.D[slot] = make_float4(0, 0, 0, __uint_as_float(0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera (sensor.h:31-33 + ray.h:9-12) and the per-sample jitter (integrator.h:384-385)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void camera_ray(const FrameParams& fp, const TileMap& tm, int x, int y, Rng& rng, f3& o, f3& d) {
+    const float u = ((float)x + rng_uniform(rng)) / (float)tm.width;
+    const float v = ((float)y + rng_uniform(rng)) / (float)tm.height;
+    const f3 org = mk3(fp.cam_origin[0], fp.cam_origin[1], fp.cam_origin[2]);
+    const f3 llc = mk3(fp.cam_llc[0], fp.cam_llc[1], fp.cam_llc[2]);
+    const f3 hor = mk3(fp.cam_hor[0], fp.cam_hor[1], fp.cam_hor[2]);
+    const f3 ver = mk3(fp.cam_ver[0], fp.cam_ver[1], fp.cam_ver[2]);
+    o = org;
+    d = unit_vector(llc + u * hor + v * ver - org);
+}
+
+__global__ __launch_bounds__(kBlock) void ptmi_frame_begin(TileMap tm, PathState st, FrameParams fp) {
+    const int n = tm.local_rows * tm.width;
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    int x, y;
+    global_pixel(tm, slot, x, y);
+    const uint4 e = st.E[slot]; const uint2 f = st.F[slot];
+    Rng rng = {e.x, e.y, e.z, e.w, f.x, f.y};
+    f3 o, d;
+    camera_ray(fp, tm, x, y, rng, o, d);
+    st.A[slot] = make_float4(o.x, o.y, o.z, 1.0f);
+    st.B[slot] = make_float4(d.x, d.y, d.z, 1.0f);
+    st.C[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    st.D[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    st.E[slot] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
+    st.F[slot] = make_uint2(rng.v4, rng.d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// primitive tests
+// ---------------------------------------------------------------------------------------------
+// Moller-Trumbore with the reference's accept/reject forms.  edge1/edge2 arrive precomputed.
+// Triangle::intersect (triangle.h:64-96): rejects |a| < eps, u<0||u>1, v<0||u+v>1; accepts t>eps && t>=t_min && t<=t_max.
+__device__ __forceinline__ bool tri_test(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float t_min, float t_max, float& t_out) {
+    const float EPSILON = 1e-8f;
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    if (fabsf(a) < EPSILON) return false;
+    const float f = rcp_rn(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(edge2, q);
+    if (t > EPSILON && t >= t_min && t <= t_max) { t_out = t; return true; }
+    return false;
+}
+// One half of Quad::intersect (quad.h:56-87 / 90-121): note the inclusive forms and the STRICT t < closest.
+__device__ __forceinline__ bool quad_half(f3 v00, f3 edge1, f3 edge2, f3 o, f3 d, float t_min, float& closest_t) {
+    const float EPSILON = 1e-8f;
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    if (fabsf(a) > EPSILON) {
+        const float f = rcp_rn(a);
+        const f3 s = o - v00;
+        const float u = f * dot(s, h);
+        if (u >= 0.0f && u <= 1.0f) {
+            const f3 q = cross(s, edge1);
+            const float v = f * dot(d, q);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                const float t = f * dot(edge2, q);
+                if (t > EPSILON && t >= t_min && t < closest_t) { closest_t = t; return true; }
+            }
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ f3 xyz(const float4& v) { return mk3(v.x, v.y, v.z); }
+
+struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits; };
+
+// Scene::intersect_bvh_optimized (scene.h:50-110).  `stack` points at this lane's column of the LDS stack
+// (entry e lives at stack[e * kBlock]).  The node about to be visited is kept in a register instead of being
+// pushed and popped again; the reference's "drop both children when stack_ptr >= 62" rule (scene.h:101-105)
+// is evaluated on the same stack_ptr value the reference would see.
+template <bool HAS_QUADS, bool STATS>
+__device__ __forceinline__ bool scene_intersect(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
+                                                int* stack, f3 o, f3 d, float t_min, float t_max,
+                                                float& t_hit, int& slot_hit, LaneCounters& cn) {
+    bool hit_anything = false;
+    float closest_t = t_max;
+    const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    int sp = 0;
+    int cur = 0;
+    while (true) {
+        if (cur < 0) {
+            if (sp == 0) break;
+            cur = stack[(--sp) * kBlock];
+        }
+        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+        if (STATS) cn.node_visits++;
+        cur = -1;
+        float tmin_box = t_min, tmax_box = closest_t;
+        {
+            float t0 = (n0.x - o.x) * inv.x, t1 = (n1.x - o.x) * inv.x;
+            if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        }
+        {
+            float t0 = (n0.y - o.y) * inv.y, t1 = (n1.y - o.y) * inv.y;
+            if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        }
+        {
+            float t0 = (n0.z - o.z) * inv.z, t1 = (n1.z - o.z) * inv.z;
+            if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        }
+        if (tmax_box < tmin_box) continue;
+        const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+        if (right < 0) {                                   // leaf: -right primitives from slot `left`
+            const int count = -right;
+            for (int i = 0; i < count; i++) {
+                const int k = left + i;
+                const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+                if (STATS) cn.prim_tests++;
+                float t;
+                bool h;
+                if (HAS_QUADS && __float_as_int(p0.w) != 0) {
+                    const float4 p3 = prims[k * prim_stride + 3];
+                    float c = closest_t;                    // Quad::intersect starts from t_max = closest_t
+                    h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);           // (v00, v10, v11)
+                    h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;      // (v00, v11, v01)
+                    t = c;
+                } else {
+                    h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
+                }
+                if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }   // scene.h:89-96
+            }
+        } else if (sp < 62) {                              // push right, visit left next (scene.h:101-105)
+            stack[(sp++) * kBlock] = right;
+            cur = left;
+        }
+    }
+    t_hit = closest_t;
+    return hit_anything;
+}
+
+// sampleCosineHemisphere (integrator.h:62-85) with the two uniforms already drawn
+__device__ __forceinline__ f3 cosine_hemisphere(f3 n, float u, float v) {
+    const float r = sqrt_rn(u);
+    const float phi = (float)((double)2.0f * PTMI_PI_D * (double)v);      // 2.0f * M_PI * v with a double M_PI
+    float sphi, cphi;
+    ptmi_sincosf(phi, &sphi, &cphi);
+    const float x = r * cphi;
+    const float y = r * sphi;
+    const float z = sqrt_rn(fmaxf(0.0f, 1.0f - u));
+    f3 tangent, bitangent;
+    if (n.z < -0.9999999f) {
+        tangent = mk3(0.0f, -1.0f, 0.0f);
+        bitangent = mk3(-1.0f, 0.0f, 0.0f);
+    } else {
+        const float a = rcp_rn(1.0f + n.z);
+        const float b = -n.x * n.y * a;
+        tangent = mk3(1.0f - n.x * n.x * a, b, -n.x);
+        bitangent = mk3(b, 1.0f - n.y * n.y * a, -n.y);
+    }
+    return unit_vector(x * tangent + y * bitangent + z * n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the hot kernel
+// ---------------------------------------------------------------------------------------------
+struct BounceArgs {
+    DeviceScene sc; TileMap tm; PathState st; FrameParams fp;
+    const int* queue_in; int n_in;
+    int* queue_out; int* count_out;
+    int segments;
+    StatCounters* stats;
+};
+
+template <bool LDS_SCENE, bool HAS_QUADS, bool STATS>
+__global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
+    extern __shared__ float4 smem[];
+    // LDS: [nodes | prims | mats] (only when LDS_SCENE) then the per-lane traversal stacks
+    const int n_node_vec = 2 * a.sc.n_nodes, n_prim_vec = a.sc.prim_stride * a.sc.n_prims, n_mat_vec = 3 * a.sc.n_prims;
+    const float4* nodes = a.sc.nodes; const float4* prims = a.sc.prims; const float4* mats = a.sc.mats;
+    int* stack_base;
+    if (LDS_SCENE) {
+        for (int i = threadIdx.x; i < n_node_vec; i += kBlock) smem[i] = a.sc.nodes[i];
+        for (int i = threadIdx.x; i < n_prim_vec; i += kBlock) smem[n_node_vec + i] = a.sc.prims[i];
+        for (int i = threadIdx.x; i < n_mat_vec; i += kBlock) smem[n_node_vec + n_prim_vec + i] = a.sc.mats[i];
+        nodes = smem; prims = smem + n_node_vec; mats = smem + n_node_vec + n_prim_vec;
+        stack_base = reinterpret_cast<int*>(smem + n_node_vec + n_prim_vec + n_mat_vec);
+        __syncthreads();
+    } else {
+        stack_base = reinterpret_cast<int*>(smem);
+    }
+    int* stack = stack_base + threadIdx.x;
+
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < a.n_in;
+    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
+    bool alive = active;
+
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), tp = mk3(1, 1, 1), L = mk3(0, 0, 0), color = mk3(0, 0, 0);
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    unsigned int meta = 0;
+    int px = 0, py = 0;
+    if (active) {
+        const float4 A = a.st.A[slot], B = a.st.B[slot], C = a.st.C[slot], D = a.st.D[slot];
+        const uint4 E = a.st.E[slot]; const uint2 F = a.st.F[slot];
+        o = xyz(A); d = xyz(B); L = xyz(C); color = xyz(D);
+        tp = mk3(A.w, B.w, C.w);
+        meta = __float_as_uint(D.w);
+        rng = Rng{E.x, E.y, E.z, E.w, F.x, F.y};
+        global_pixel(a.tm, slot, px, py);
+    }
+    unsigned int sample_idx = meta >> 8;
+    int depth = (int)(meta & 0xffu);
+    LaneCounters cn = {0, 0, 0, 0};
+
+    for (int seg = 0; seg < a.segments; seg++) {
+        if (!__any(alive)) break;
+        if (alive) {
+            float t; int k = -1;
+            if (STATS) cn.rays++;
+            const bool hit = scene_intersect<HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, stack, o, d, 1e-4f, FLT_MAX, t, k, cn);
+            bool end_sample = !hit;                                                   // integrator.h:198-201
+            if (hit) {
+                if (STATS) cn.hits++;
+                const f3 n = xyz(mats[3 * k]), bsdf = xyz(mats[3 * k + 1]), Le = xyz(mats[3 * k + 2]);
+                const f3 p = o + t * d;                                               // triangle.h:90
+                L = L + tp * Le;                                                      // integrator.h:204
+                if (depth > 2) {                                                      // integrator.h:207-212
+                    const float max_tp = fmaxf(tp.x, fmaxf(tp.y, tp.z));
+                    const float rr_prob = fminf(max_tp, 0.95f);
+                    if (rng_uniform(rng) > rr_prob) end_sample = true;
+                    else tp = div_scalar(tp, rr_prob);
+                }
+                if (!end_sample) {
+                    tp = tp * bsdf;                                                   // integrator.h:215
+                    if (length(tp) < 1e-5f) end_sample = true;                        // integrator.h:218
+                    else {
+                        const f3 sn = dot(d, n) < 0 ? n : -n;                         // integrator.h:221-222
+                        const float u = rng_uniform(rng);                             // integrator.h:63-64
+                        const float v = rng_uniform(rng);
+                        depth++;
+                        if (depth < a.fp.max_depth) {
+                            const f3 next = cosine_hemisphere(sn, u, v);              // integrator.h:230
+                            o = p + 1e-4f * sn;                                       // integrator.h:266
+                            d = unit_vector(next);                                    // Ray ctor normalises again
+                        } else end_sample = true;                                     // loop bound; the draws above are still consumed
+                    }
+                }
+            }
+            if (end_sample) {
+                color = color + L;                                                    // integrator.h:390
+                sample_idx++;
+                if (sample_idx < (unsigned int)a.fp.spp) {                            // next iteration of the spp loop
+                    camera_ray(a.fp, a.tm, px, py, rng, o, d);
+                    tp = mk3(1.0f, 1.0f, 1.0f); L = mk3(0.0f, 0.0f, 0.0f); depth = 0;
+                } else alive = false;
+            }
+        }
+    }
+
+    if (active) {
+        a.st.A[slot] = make_float4(o.x, o.y, o.z, tp.x);
+        a.st.B[slot] = make_float4(d.x, d.y, d.z, tp.y);
+        a.st.C[slot] = make_float4(L.x, L.y, L.z, tp.z);
+        a.st.D[slot] = make_float4(color.x, color.y, color.z, __uint_as_float((sample_idx << 8) | (unsigned int)depth));
+        a.st.E[slot] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
+        a.st.F[slot] = make_uint2(rng.v4, rng.d);
+    }
+
+    // active-path compaction: one atomic per wave reserves queue space, lanes scatter by prefix popcount
+    {
+        const unsigned long long mask = __ballot(alive);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(a.count_out, __popcll(mask));
+        base = __shfl(base, 0);
+        if (alive) a.queue_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    }
+
+    if (STATS) {
+        unsigned long long r = cn.rays, nv = cn.node_visits, pt = cn.prim_tests, h = cn.hits;
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_down(r, off); nv += __shfl_down(nv, off); pt += __shfl_down(pt, off); h += __shfl_down(h, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&a.stats->rays, r); atomicAdd(&a.stats->node_visits, nv);
+            atomicAdd(&a.stats->prim_tests, pt); atomicAdd(&a.stats->hits, h);
+        }
+    }
+}
+
+size_t bounce_lds_bytes(const DeviceScene& sc) {
+    size_t b = (size_t)sc.stack_entries * kBlock * sizeof(int);
+    if (sc.lds_resident) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);
+    return b;
+}
+
+void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
+                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
+                   StatCounters* stats, hipStream_t s) {
+    if (n_in <= 0) return;
+    BounceArgs a{sc, tm, st, fp, queue_in, n_in, queue_out, count_out, segments, stats};
+    const dim3 grid((n_in + kBlock - 1) / kBlock), block(kBlock);
+    const size_t lds = bounce_lds_bytes(sc);
+#define PTMI_LAUNCH(L_, Q_, S_) hipLaunchKernelGGL((ptmi_bounce<L_, Q_, S_>), grid, block, lds, s, a)
+    const int key = (sc.lds_resident ? 4 : 0) | (sc.has_quads ? 2 : 0) | (stats ? 1 : 0);
+    switch (key) {
+        case 0: PTMI_LAUNCH(false, false, false); break;
+        case 1: PTMI_LAUNCH(false, false, true); break;
+        case 2: PTMI_LAUNCH(false, true, false); break;
+        case 3: PTMI_LAUNCH(false, true, true); break;
+        case 4: PTMI_LAUNCH(true, false, false); break;
+        case 5: PTMI_LAUNCH(true, false, true); break;
+        case 6: PTMI_LAUNCH(true, true, false); break;
+        default: PTMI_LAUNCH(true, true, true); break;
+    }
+#undef PTMI_LAUNCH
+}
+
+void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* d_jump, uint64_t seed_base, hipStream_t s) {
+    const int n = tm.local_rows * tm.width;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ptmi_render_init, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, d_jump,
+                       (unsigned long long)seed_base);
+}
+
+void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParams& fp, hipStream_t s) {
+    const int n = tm.local_rows * tm.width;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ptmi_frame_begin, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, fp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// resolve: color /= spp; Reinhard; gamma 1/2.2; 8-bit (integrator.h:393-407)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ptmi_resolve(TileMap tm, PathState st, int spp, unsigned char* __restrict__ rgb8,
+                                                       float* __restrict__ radiance) {
+    const int n = tm.local_rows * tm.width;
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    const float4 D = st.D[slot];
+    const float k = rcp_rn((float)spp);                    // Vector::operator/=(T): T k = 1.0 / t (vector.h:90-94)
+    const float c[3] = {D.x * k, D.y * k, D.z * k};
+    const float gamma = 1.0f / 2.2f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        if (radiance) radiance[(size_t)slot * 3 + ch] = c[ch];
+        if (rgb8) {
+            const float tm_ = c[ch] / (c[ch] + 1.0f);       // color / (color + 1), component-wise true division
+            const float g = ptmi_powf(tm_, gamma);
+            rgb8[(size_t)slot * 3 + ch] = (unsigned char)(255.99f * fminf(g, 1.0f));
+        }
+    }
+}
+
+void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s) {
+    const int n = tm.local_rows * tm.width;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ptmi_resolve, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, spp, rgb8, radiance);
+}
+
+// ---------------------------------------------------------------------------------------------
+// test hooks
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_QUADS>
+__global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_k(DeviceScene sc, int n, const float* o, const float* d, float t_min,
+                                                                 float t_max, int* hit, int* prim, float* t_out, float* p_out, float* n_out) {
+    extern __shared__ float4 smem[];
+    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    LaneCounters cn = {0, 0, 0, 0};
+    float t = 0.0f; int k = -1;
+    const bool h = scene_intersect<HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, stack, ro, rd, t_min, t_max, t, k, cn);
+    hit[i] = h ? 1 : 0;
+    prim[i] = h ? __float_as_int(sc.mats[3 * k].w) : -1;
+    t_out[i] = h ? t : 0.0f;
+    const f3 p = h ? ro + t * rd : mk3(0, 0, 0);
+    const f3 nn = h ? xyz(sc.mats[3 * k]) : mk3(0, 0, 0);
+    p_out[3 * i] = p.x; p_out[3 * i + 1] = p.y; p_out[3 * i + 2] = p.z;
+    n_out[3 * i] = nn.x; n_out[3 * i + 1] = nn.y; n_out[3 * i + 2] = nn.z;
+}
+
+void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
+                            int* hit, int* prim, float* t, float* p, float* nrm, hipStream_t s) {
+    if (n <= 0) return;
+    const size_t lds = (size_t)sc.stack_entries * kBlock * sizeof(int);
+    const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    if (sc.has_quads) hipLaunchKernelGGL(ptmi_debug_intersect_k<true>, grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm);
+    else hipLaunchKernelGGL(ptmi_debug_intersect_k<false>, grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm);
+}
+
+__global__ void ptmi_debug_rng_k(const uint32_t* __restrict__ jump, unsigned long long seed_base, int n_pixels,
+                                 const int* pixels, int count, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const unsigned int pix = (unsigned int)pixels[i];
+    const unsigned long long seed = seed_base + (unsigned long long)pix;
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    for (int k = 0; k < 32; k++) {
+        if (!((pix >> k) & 1u)) continue;
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < 5; w++)
+            for (int b = 0; b < 32; b++)
+                if ((v[w] >> b) & 1u) for (int c = 0; c < 5; c++) r[c] ^= jump[(k * 160 + w * 32 + b) * 5 + c];
+        for (int w = 0; w < 5; w++) v[w] = r[w];
+    }
+    Rng rng = {v[0], v[1], v[2], v[3], v[4], 6615241u + t1 + t0};
+    for (int c = 0; c < count; c++) out[(size_t)i * count + c] = rng_uniform(rng);
+}
+
+void launch_debug_rng(const uint32_t* d_jump, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out, hipStream_t s) {
+    if (n_pixels <= 0) return;
+    hipLaunchKernelGGL(ptmi_debug_rng_k, dim3((n_pixels + 63) / 64), dim3(64), 0, s, d_jump, (unsigned long long)seed_base,
+                       n_pixels, pixels, count, out);
+}
+
+__global__ void ptmi_debug_cosine_k(int n, const float* normals, const float* u, const float* v, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 r = cosine_hemisphere(mk3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]), u[i], v[i]);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+
+void launch_debug_cosine(int n, const float* normals, const float* u, const float* v, float* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ptmi_debug_cosine_k, dim3((n + 255) / 256), dim3(256), 0, s, n, normals, u, v, out);
+}
+
+}  // namespace ptmi

@@ -1,0 +1,345 @@
+#include "application_state.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+
+namespace ptmi {
+
+#define PTMI_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) throw HipError(e_, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+void* hipMallocSafe(size_t bytes, const char* name) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) throw HipError(e, std::string("hipMalloc(") + name + ", " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// XORWOW skip-ahead matrices
+// ------------------------------------------------------------------------------------------------
+namespace {
+using Mat = std::vector<uint32_t>;   // 160 rows x 5 words; row b = image of basis state bit b
+void stepV(uint32_t v[5]) {
+    const uint32_t t = v[0] ^ (v[0] >> 2);
+    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+void apply(const Mat& m, const uint32_t* in, uint32_t* out) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < 160; b++)
+        if ((in[b >> 5] >> (b & 31)) & 1u) for (int c = 0; c < 5; c++) r[c] ^= m[b * 5 + c];
+    std::memcpy(out, r, sizeof r);
+}
+Mat square(const Mat& m) {
+    Mat s(160 * 5);
+    for (int b = 0; b < 160; b++) apply(m, &m[b * 5], &s[b * 5]);
+    return s;
+}
+}  // namespace
+
+std::vector<uint32_t> buildXorwowJumpMatrices() {
+    Mat m(160 * 5);
+    for (int b = 0; b < 160; b++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[b >> 5] = 1u << (b & 31);
+        stepV(v);
+        std::memcpy(&m[b * 5], v, sizeof v);
+    }
+    for (int s = 0; s < 67; s++) m = square(m);          // one subsequence = 2^67 draws
+    std::vector<uint32_t> all;
+    all.reserve(kXorwowJumpWords);
+    for (int k = 0; k < 32; k++) {
+        all.insert(all.end(), m.begin(), m.end());
+        if (k != 31) m = square(m);
+    }
+    return all;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiling
+// ------------------------------------------------------------------------------------------------
+int countLocalRows(int height, int n_ranks, int rank, int row_block) {
+    int rows = 0;
+    for (int y0 = rank * row_block; y0 < height; y0 += n_ranks * row_block) rows += std::min(row_block, height - y0);
+    return rows;
+}
+std::vector<int> localRowMap(const TileMap& tm) {
+    std::vector<int> rows;
+    for (int y0 = tm.rank * tm.row_block; y0 < tm.height; y0 += tm.n_ranks * tm.row_block)
+        for (int y = y0; y < std::min(y0 + tm.row_block, tm.height); y++) rows.push_back(y);
+    return rows;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SceneState
+// ------------------------------------------------------------------------------------------------
+void SceneState::cleanup() {
+    if (d_nodes) (void)hipFree(d_nodes);
+    if (d_prims) (void)hipFree(d_prims);
+    if (d_mats) (void)hipFree(d_mats);
+    d_nodes = d_prims = d_mats = nullptr;
+    d_scene = DeviceScene();
+    h_primitives.clear(); bvh_nodes.clear(); bvh_indices.clear();
+    num_tris = num_quads = 0; bvh_depth = 0;
+}
+
+void SceneState::loadScene(const std::string& filename, int subdivision_count, bool convert_quads) {
+    loadSceneHost(filename, subdivision_count, convert_quads);
+    upload();
+}
+
+void SceneState::loadSceneArrays(std::vector<Primitive> prims) {
+    loadSceneArraysHost(std::move(prims));
+    upload();
+}
+
+void SceneState::loadSceneHost(const std::string& filename, int subdivision_count, bool convert_quads) {
+    cleanup();
+    const size_t dot = filename.find_last_of('.');
+    if (dot == std::string::npos) throw IoError("unsupported file format (no extension): " + filename);
+    std::string ext = filename.substr(dot);
+    std::transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    if (ext != ".obj") throw IoError("unsupported file format: " + ext);          // .pbrt is out of scope (USE_PBRT_LOADER off)
+
+    std::vector<Primitive> prims;
+    if (!loadOBJ(filename, prims)) throw IoError("failed to load scene: " + filename);
+    if (convert_quads) prims = convertQuadsToTriangles(prims);
+    if (subdivision_count > 0) prims = subdivide_primitives(prims, subdivision_count);
+    h_primitives.swap(prims);
+    scene_file = filename;
+    buildBVH();
+}
+
+void SceneState::loadSceneArraysHost(std::vector<Primitive> prims) {
+    cleanup();
+    if (prims.empty()) throw ArgError("scene has no primitives");
+    h_primitives.swap(prims);
+    scene_file = "<arrays>";
+    buildBVH();
+}
+
+void SceneState::buildBVH() {
+    const int n = (int)h_primitives.size();
+    BVHBuilder builder(h_primitives.data(), n);
+    bvh_nodes = builder.nodes;
+    bvh_indices = builder.primitive_indices;
+    bvh_depth = builder.max_depth;
+    num_tris = num_quads = 0;
+    for (const Primitive& p : h_primitives) (p.type == PRIM_TRIANGLE ? num_tris : num_quads)++;
+}
+
+void SceneState::upload() {
+    const int n = (int)h_primitives.size();
+    // ---- SoA re-layout (device_scene.h) ----
+    const int stride = num_quads ? 4 : 3;
+    auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
+    std::vector<float4> nodes(2 * bvh_nodes.size()), prims((size_t)stride * n), mats((size_t)3 * n);
+    for (size_t i = 0; i < bvh_nodes.size(); i++) {
+        const BVHNode& b = bvh_nodes[i];
+        nodes[2 * i] = make_float4(b.bbox.min.x, b.bbox.min.y, b.bbox.min.z, bits(b.left_child));
+        nodes[2 * i + 1] = make_float4(b.bbox.max.x, b.bbox.max.y, b.bbox.max.z, bits(b.isLeaf() ? -b.prim_count : b.right_child));
+    }
+    for (int k = 0; k < n; k++) {                     // k = leaf-order slot
+        const int src = bvh_indices[k];
+        const Primitive& p = h_primitives[src];
+        const f3 e1 = p.v[1] - p.v[0], e2 = p.v[2] - p.v[0];
+        prims[(size_t)stride * k] = make_float4(p.v[0].x, p.v[0].y, p.v[0].z, bits(p.type == PRIM_QUAD ? 1 : 0));
+        prims[(size_t)stride * k + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+        prims[(size_t)stride * k + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        if (stride == 4) {
+            const f3 e3 = p.type == PRIM_QUAD ? p.v[3] - p.v[0] : mk3(0, 0, 0);
+            prims[(size_t)stride * k + 3] = make_float4(e3.x, e3.y, e3.z, 0.0f);
+        }
+        mats[(size_t)3 * k] = make_float4(p.normal.x, p.normal.y, p.normal.z, bits(src));
+        mats[(size_t)3 * k + 1] = make_float4(p.bsdf.x, p.bsdf.y, p.bsdf.z, 0.0f);
+        mats[(size_t)3 * k + 2] = make_float4(p.Le.x, p.Le.y, p.Le.z, 0.0f);
+    }
+    d_nodes = (float4*)hipMallocSafe(nodes.size() * sizeof(float4), "d_nodes");
+    d_prims = (float4*)hipMallocSafe(prims.size() * sizeof(float4), "d_prims");
+    d_mats = (float4*)hipMallocSafe(mats.size() * sizeof(float4), "d_mats");
+    PTMI_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PTMI_HIP(hipMemcpy(d_prims, prims.data(), prims.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PTMI_HIP(hipMemcpy(d_mats, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
+
+    d_scene.nodes = d_nodes; d_scene.prims = d_prims; d_scene.mats = d_mats;
+    d_scene.n_nodes = (int)bvh_nodes.size(); d_scene.n_prims = n;
+    d_scene.prim_stride = stride; d_scene.has_quads = num_quads ? 1 : 0;
+    d_scene.stack_entries = std::min(bvh_depth + 1, 64);
+    // LDS residency: the whole scene is staged per workgroup while it leaves room for >= 2 workgroups per CU
+    const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
+    d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RenderState
+// ------------------------------------------------------------------------------------------------
+void RenderState::freeBuffers() {
+    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance,
+                    d_queue[0], d_queue[1], d_count, d_stats};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h_count) (void)hipHostFree(h_count);
+    d_state = PathState();
+    d_image = nullptr; d_radiance = nullptr; d_queue[0] = d_queue[1] = nullptr; d_count = nullptr; d_stats = nullptr; h_count = nullptr;
+    n_local = 0;
+}
+
+void RenderState::allocateBuffers() {
+    freeBuffers();
+    tile.width = width; tile.height = height;
+    tile.local_rows = countLocalRows(height, tile.n_ranks, tile.rank, tile.row_block);
+    n_local = (size_t)tile.local_rows * (size_t)width;
+    const size_t n = std::max<size_t>(n_local, 1);
+    d_state.A = (float4*)hipMallocSafe(n * sizeof(float4), "state.A");
+    d_state.B = (float4*)hipMallocSafe(n * sizeof(float4), "state.B");
+    d_state.C = (float4*)hipMallocSafe(n * sizeof(float4), "state.C");
+    d_state.D = (float4*)hipMallocSafe(n * sizeof(float4), "state.D");
+    d_state.E = (uint4*)hipMallocSafe(n * sizeof(uint4), "state.E");
+    d_state.F = (uint2*)hipMallocSafe(n * sizeof(uint2), "state.F");
+    d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
+    d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
+    d_queue[0] = (int*)hipMallocSafe(n * sizeof(int), "d_queue0");
+    d_queue[1] = (int*)hipMallocSafe(n * sizeof(int), "d_queue1");
+    d_count = (int*)hipMallocSafe(2 * sizeof(int), "d_count");
+    d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
+    PTMI_HIP(hipHostMalloc((void**)&h_count, 2 * sizeof(int)));
+
+    // camera: image size + aspect, then updateCamera (application_state.h:106-109)
+    h_camera.image_width = width; h_camera.image_height = height;
+    h_camera.aspect = (float)width / (float)height;
+    h_camera.updateCamera();
+
+    // render_init (application_state.h:120-122): streams are re-seeded on every (re)allocation
+    launch_render_init(tile, d_state, d_jump, seed_base, stream);
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipStreamSynchronize(stream));
+}
+
+void RenderState::updateResolution(int w, int h, const TileMap* tiling) {
+    if (w <= 0 || h <= 0) throw ArgError("width and height must be positive");
+    if ((long long)w * h > (1ll << 31) - 1) throw ArgError("frame has more than 2^31-1 pixels");
+    if (tiling) {
+        if (tiling->n_ranks < 1 || tiling->rank < 0 || tiling->rank >= tiling->n_ranks || tiling->row_block < 1)
+            throw ArgError("bad tiling (need n_ranks >= 1, 0 <= rank < n_ranks, row_block >= 1)");
+        tile.n_ranks = tiling->n_ranks; tile.rank = tiling->rank; tile.row_block = tiling->row_block;
+    } else { tile.n_ranks = 1; tile.rank = 0; tile.row_block = 8; }
+    width = w; height = h;
+    allocateBuffers();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ApplicationState / renderFrame
+// ------------------------------------------------------------------------------------------------
+ApplicationState::ApplicationState(int device) : device_id(device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw HipError(e == hipSuccess ? hipErrorNoDevice : e, "no HIP device available (libptmi has no CPU fallback)");
+    if (device < 0 || device >= count) throw ArgError("device_id out of range");
+    PTMI_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PTMI_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        throw HipError(hipErrorInvalidDevice, std::string("libptmi is built for gfx950 only; device is ") + prop.gcnArchName);
+    PTMI_HIP(hipStreamCreateWithFlags(&render.stream, hipStreamNonBlocking));
+    h_jump = buildXorwowJumpMatrices();
+    render.d_jump = (uint32_t*)hipMallocSafe(h_jump.size() * sizeof(uint32_t), "d_jump");
+    PTMI_HIP(hipMemcpy(render.d_jump, h_jump.data(), h_jump.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    render.h_camera = Sensor(config.camera_origin, config.look_at, config.up, config.fov, 1.0f);   // application.h:107-113
+}
+
+ApplicationState::~ApplicationState() {
+    (void)hipSetDevice(device_id);
+    for (hipEvent_t ev : event_pool) (void)hipEventDestroy(ev);
+    scene.cleanup();
+    render.freeBuffers();
+    if (render.d_jump) (void)hipFree(render.d_jump);
+    if (render.stream) (void)hipStreamDestroy(render.stream);
+}
+
+void renderFrame(ApplicationState& g, FrameStats* stats) {
+    RenderState& r = g.render;
+    if (!g.scene.d_nodes) throw ArgError("renderFrame: no scene loaded");
+    if (!r.d_state.A) throw ArgError("renderFrame: buffers not allocated (call updateResolution first)");
+    if (g.config.sampling_mode != SamplingMode::SAMPLING_BSDF) throw ArgError("only SAMPLING_BSDF is implemented");
+    if (g.config.spp < 1 || g.config.spp >= (1 << 24)) throw ArgError("spp must be in [1, 2^24)");
+    if (g.config.max_depth < 1 || g.config.max_depth > 255) throw ArgError("max_depth must be in [1, 255]");
+    PTMI_HIP(hipSetDevice(g.device_id));
+
+    // camera update (application.h:161-163)
+    if (g.config.orbit) r.h_camera.updateCameraOrbit(); else r.h_camera.updateCamera();
+    const CameraFrame cf = r.h_camera.frame();
+    FrameParams fp;
+    const f3* src[4] = {&cf.origin, &cf.lower_left_corner, &cf.horizontal, &cf.vertical};
+    float* dst[4] = {fp.cam_origin, fp.cam_llc, fp.cam_hor, fp.cam_ver};
+    for (int i = 0; i < 4; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
+
+    const int n_local = (int)r.n_local;
+    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 8;
+    hipStream_t s = r.stream;
+    const bool want_stats = g.config.collect_stats;
+
+    auto event = [&](size_t i) {
+        while (g.event_pool.size() <= i) { hipEvent_t ev; PTMI_HIP(hipEventCreate(&ev)); g.event_pool.push_back(ev); }
+        return g.event_pool[i];
+    };
+    size_t n_ev = 0;
+    const hipEvent_t ev_begin = event(n_ev++);
+    PTMI_HIP(hipEventRecord(ev_begin, s));
+    if (want_stats) PTMI_HIP(hipMemsetAsync(r.d_stats, 0, sizeof(StatCounters), s));
+
+    launch_frame_begin(r.tile, r.d_state, fp, s);
+
+    // queue-driven loop: every launch advances each active pixel by `segments` ray segments and compacts
+    int n_active = n_local;
+    const int* q_in = nullptr;                         // identity queue for the first launch
+    int cur = 0;
+    uint64_t launches = 0;
+    const size_t first_kernel_event = n_ev;
+    while (n_active > 0) {
+        PTMI_HIP(hipMemsetAsync(r.d_count, 0, sizeof(int), s));
+        const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
+        if (stats) PTMI_HIP(hipEventRecord(e0, s));
+        launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, q_in, n_active, r.d_queue[cur], r.d_count, segments,
+                      want_stats ? r.d_stats : nullptr, s);
+        const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
+        if (stats) PTMI_HIP(hipEventRecord(e1, s));
+        PTMI_HIP(hipMemcpyAsync(r.h_count, r.d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+        PTMI_HIP(hipStreamSynchronize(s));
+        n_active = r.h_count[0];
+        q_in = r.d_queue[cur];
+        cur ^= 1;
+        launches++;
+    }
+    launch_resolve(r.tile, r.d_state, g.config.spp, r.d_image, r.d_radiance, s);
+    const hipEvent_t ev_end = event(n_ev++);
+    PTMI_HIP(hipEventRecord(ev_end, s));
+    PTMI_HIP(hipStreamSynchronize(s));                 // cudaDeviceSynchronize, application.h:199
+    PTMI_HIP(hipGetLastError());
+
+    if (stats) {
+        float ms = 0.0f;
+        PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        stats->seconds = ms * 1e-3;
+        double kms = 0.0;
+        for (size_t i = first_kernel_event; i + 1 < n_ev - 1; i += 2) {
+            float k = 0.0f;
+            PTMI_HIP(hipEventElapsedTime(&k, g.event_pool[i], g.event_pool[i + 1]));
+            kms += k;
+        }
+        stats->bounce_kernel_ms = kms;
+        stats->bounce_launches = launches;
+        stats->samples = (uint64_t)n_local * (uint64_t)g.config.spp;
+        if (want_stats) {
+            StatCounters c;
+            PTMI_HIP(hipMemcpy(&c, r.d_stats, sizeof c, hipMemcpyDeviceToHost));
+            stats->rays = c.rays; stats->node_visits = c.node_visits; stats->prim_tests = c.prim_tests; stats->hits = c.hits;
+        }
+    }
+}
+
+}  // namespace ptmi

@@ -1,0 +1,121 @@
+// application_state.h — host-side mirror of the reference's state objects for the render path
+// (include/application_state.h: RenderState :77-130, SceneState :136-256/367-490, AppConfig :262-293,
+//  ApplicationState :299-308; renderFrame: include/application.h:157-216).
+//
+// Differences by design: no global g_state (a ptmi_ctx owns one ApplicationState per GPU), no GL/ImGui,
+// no radiosity/grid-guiding members, device memory is SoA (csrc/device_scene.h) instead of the 4364-byte
+// Primitive records, and the render loop is a queue-driven sequence of ptmi_bounce launches instead of
+// one thread-per-pixel megakernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../csrc/device_scene.h"
+#include "bvh.h"
+#include "file_manager.h"
+#include "sensor.h"
+
+namespace ptmi {
+
+struct HipError : std::runtime_error {
+    hipError_t code;
+    HipError(hipError_t c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// cudaMallocSafe (utils/cuda_utils.h:54-60): throws on failure
+void* hipMallocSafe(size_t bytes, const char* name);
+
+enum class SamplingMode { SAMPLING_BSDF = 0, SAMPLING_FORMFACTOR = 1, SAMPLING_RADIOSITY = 2, SAMPLING_MIS = 3, SAMPLING_TOPK = 4 };   // render_config.h:38-44
+
+struct AppConfig {                                   // application_state.h:262-293 (path-relevant members)
+    int spp = 1;
+    int max_depth = 5;                               // literal 5 in integrator.h:389
+    SamplingMode sampling_mode = SamplingMode::SAMPLING_BSDF;
+    uint64_t seed_base = 2023;                       // integrator.h:279
+    f3 camera_origin = {0.5f, 3.0f, 8.5f}, look_at = {0.0f, 2.5f, 0.0f}, up = {0.0f, 1.0f, 0.0f};
+    float fov = 40.0f;
+    bool convert_quads_to_triangles = false;
+    bool orbit = true;                               // renderFrame() always calls updateCameraOrbit()
+    int segments_per_launch = 0;                     // 0 = default
+    bool collect_stats = false;
+};
+
+struct SceneState {
+    std::vector<Primitive> h_primitives;             // load order
+    std::vector<BVHNode> bvh_nodes;                  // pre-order
+    std::vector<int> bvh_indices;                    // leaf order -> load order
+    int bvh_depth = 0;
+    int num_tris = 0, num_quads = 0;
+    std::string scene_file;
+
+    float4 *d_nodes = nullptr, *d_prims = nullptr, *d_mats = nullptr;
+    DeviceScene d_scene;
+
+    // loadScene — application_state.h:367-464.  Throws IoError where the reference prints and returns.
+    void loadScene(const std::string& filename, int subdivision_count, bool convert_quads);
+    void loadSceneArrays(std::vector<Primitive> prims);
+    // host half only (parse + convert + subdivide + BVH), no device involved
+    void loadSceneHost(const std::string& filename, int subdivision_count, bool convert_quads);
+    void loadSceneArraysHost(std::vector<Primitive> prims);
+    void cleanup();                                  // application_state.h:466-490
+    ~SceneState() { cleanup(); }
+
+private:
+    void buildBVH();                                 // RayTracingManager::buildAccelStructure (ray_tracing_backend.h:81-129)
+    void upload();                                   // SoA re-layout + H2D
+};
+
+struct RenderState {
+    int width = 800, height = 800;                   // DEFAULT_WIDTH/HEIGHT, application_state.h:42-43
+    TileMap tile;                                    // rows of the frame this GPU renders
+    Sensor h_camera;
+    PathState d_state;                               // path state + RNG (replaces d_rand_state)
+    unsigned char* d_image = nullptr;                // RGB8, local rows
+    float* d_radiance = nullptr;                     // float3 mean radiance, local rows
+    int *d_queue[2] = {nullptr, nullptr}, *d_count = nullptr;
+    int* h_count = nullptr;                          // pinned
+    StatCounters* d_stats = nullptr;
+    uint32_t* d_jump = nullptr;                      // XORWOW skip-ahead matrices (owned by the ctx, set before allocateBuffers)
+    uint64_t seed_base = 2023;
+    hipStream_t stream = nullptr;
+    size_t n_local = 0;
+
+    void allocateBuffers();                          // application_state.h:91-123 (+ render_init)
+    void updateResolution(int w, int h, const TileMap* tiling);   // application_state.h:125-129
+    void freeBuffers();
+    ~RenderState() { freeBuffers(); }
+};
+
+struct FrameStats {
+    double seconds = 0, bounce_kernel_ms = 0;
+    uint64_t bounce_launches = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0;
+};
+
+struct ApplicationState {
+    int device_id = 0;
+    RenderState render;
+    SceneState scene;
+    AppConfig config;
+    std::vector<uint32_t> h_jump;                    // 32 x 160 x 5 words
+    std::vector<hipEvent_t> event_pool;
+
+    explicit ApplicationState(int device);
+    ~ApplicationState();
+};
+
+// renderFrame — application.h:157-216: camera update, launches, device sync.  Results stay on the device.
+void renderFrame(ApplicationState& g_state, FrameStats* stats);
+
+// GF(2) matrices T^(2^67 * 2^k), k = 0..31, of the xorwow state transition (cuRAND's subsequence skip-ahead).
+std::vector<uint32_t> buildXorwowJumpMatrices();
+
+std::vector<int> localRowMap(const TileMap& tm);
+int countLocalRows(int height, int n_ranks, int rank, int row_block);
+
+}  // namespace ptmi

@@ -1,0 +1,322 @@
+"""ctypes binding of libptmi.so (include/ptmi.h) — the product path.
+
+No fallback: if the shared library is missing or no gfx950 device is usable, construction
+raises.  Mirrors the reference's three host entry points:
+
+    Renderer.load_scene(path, subdivision, convert_quads)   ~ SceneState::loadScene
+    Renderer.update_resolution(w, h, tiling)                 ~ RenderState::updateResolution
+    Renderer.render_frame()                                  ~ renderFrame()
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libptmi.so")
+
+EXPORTS = [
+    "ptmi_ctx_create", "ptmi_ctx_destroy", "ptmi_last_error", "ptmi_default_camera", "ptmi_default_config",
+    "ptmi_default_tiling", "ptmi_load_scene", "ptmi_load_scene_arrays", "ptmi_scene_info", "ptmi_scene_get_prims",
+    "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
+    "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
+    "ptmi_copy_image_device",
+    "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample",
+    "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
+    "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
+]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lookat", C.c_float * 3), ("vup", C.c_float * 3),
+                ("vfov_deg", C.c_float), ("yaw_deg", C.c_float), ("pitch_deg", C.c_float), ("orbit", C.c_int)]
+
+
+class Config(C.Structure):
+    _fields_ = [("spp", C.c_int), ("max_depth", C.c_int), ("sampling_mode", C.c_int), ("seed_base", C.c_uint64),
+                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int)]
+
+
+class Tiling(C.Structure):
+    _fields_ = [("n_ranks", C.c_int), ("rank", C.c_int), ("row_block", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64),
+                ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
+                ("prim_tests", C.c_uint64), ("hits", C.c_uint64)]
+
+
+class PtmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ptmi error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libptmi.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C cuda-pathtracer_amd` "
+                               f"(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.ptmi_last_error.restype = C.c_char_p
+        vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p
+        L.ptmi_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ptmi_ctx_destroy.argtypes = [vp]; L.ptmi_ctx_destroy.restype = None
+        L.ptmi_default_camera.argtypes = [C.POINTER(Camera)]; L.ptmi_default_camera.restype = None
+        L.ptmi_default_config.argtypes = [C.POINTER(Config)]; L.ptmi_default_config.restype = None
+        L.ptmi_default_tiling.argtypes = [C.POINTER(Tiling)]; L.ptmi_default_tiling.restype = None
+        L.ptmi_load_scene.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.ptmi_load_scene_arrays.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+        L.ptmi_scene_info.argtypes = [vp, ip, ip, ip, ip, ip]
+        L.ptmi_scene_get_prims.argtypes = [vp] * 6
+        L.ptmi_scene_get_bvh.argtypes = [vp] * 7
+        L.ptmi_update_resolution.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Tiling)]
+        L.ptmi_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        L.ptmi_set_config.argtypes = [vp, C.POINTER(Config)]
+        L.ptmi_get_camera_frame.argtypes = [vp, fp]
+        L.ptmi_local_rows.argtypes = [vp, ip]
+        L.ptmi_local_row_map.argtypes = [vp, vp]
+        L.ptmi_render_frame.argtypes = [vp, C.POINTER(Stats)]
+        L.ptmi_device_image.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.ptmi_read_image.argtypes = [vp, vp, vp]
+        L.ptmi_copy_image_device.argtypes = [vp, vp, vp]
+        L.ptmi_debug_intersect.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
+        L.ptmi_debug_rng.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_int, vp]
+        L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.ptmi_host_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ptmi_host_scene_from_arrays.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.POINTER(vp)]
+        L.ptmi_host_scene_free.argtypes = [vp]; L.ptmi_host_scene_free.restype = None
+        L.ptmi_host_scene_info.argtypes = [vp, ip, ip, ip, ip, ip]
+        L.ptmi_host_scene_get_prims.argtypes = [vp] * 6
+        L.ptmi_host_scene_get_bvh.argtypes = [vp] * 7
+        L.ptmi_host_camera_frame.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, vp]
+        L.ptmi_host_local_row_map.argtypes = [C.c_int, C.POINTER(Tiling), ip, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtmiError(rc, lib().ptmi_last_error().decode(errors="replace"))
+
+
+class HostScene:
+    """Host half of loadScene (parse, convert, subdivide, BVH) - needs no GPU."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def load(cls, filename, subdivision_count=0, convert_quads=False):
+        h = C.c_void_p()
+        _check(lib().ptmi_host_scene_load(os.fsencode(filename), int(subdivision_count), int(bool(convert_quads)), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, types, verts, normal, bsdf, Le):
+        types = np.ascontiguousarray(types, np.int32)
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 4, 3)
+        normal, bsdf, Le = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (normal, bsdf, Le))
+        h = C.c_void_p()
+        _check(lib().ptmi_host_scene_from_arrays(len(types), types.ctypes.data, verts.ctypes.data, normal.ctypes.data,
+                                                 bsdf.ctypes.data, Le.ctypes.data, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        try:
+            if self.h and self.h.value:
+                lib().ptmi_host_scene_free(self.h)
+        except Exception:
+            pass
+
+    def info(self):
+        v = [C.c_int() for _ in range(5)]
+        _check(lib().ptmi_host_scene_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_prims", "n_tris", "n_quads", "n_bvh_nodes", "bvh_depth"), (x.value for x in v)))
+
+    def prims(self):
+        n = self.info()["n_prims"]
+        t = np.zeros(n, np.int32); v = np.zeros((n, 4, 3), np.float32)
+        nr = np.zeros((n, 3), np.float32); b = np.zeros((n, 3), np.float32); le = np.zeros((n, 3), np.float32)
+        _check(lib().ptmi_host_scene_get_prims(self.h, t.ctypes.data, v.ctypes.data, nr.ctypes.data, b.ctypes.data, le.ctypes.data))
+        return dict(type=t, verts=v, normal=nr, bsdf=b, Le=le)
+
+    def bvh(self):
+        info = self.info(); n, m = info["n_bvh_nodes"], info["n_prims"]
+        bmin = np.zeros((n, 3), np.float32); bmax = np.zeros((n, 3), np.float32)
+        left = np.zeros(n, np.int32); right = np.zeros(n, np.int32); count = np.zeros(n, np.int32); idx = np.zeros(m, np.int32)
+        _check(lib().ptmi_host_scene_get_bvh(self.h, bmin.ctypes.data, bmax.ctypes.data, left.ctypes.data, right.ctypes.data,
+                                             count.ctypes.data, idx.ctypes.data))
+        return dict(bmin=bmin, bmax=bmax, left=left, right=right, count=count, indices=idx)
+
+
+def host_camera_frame(cam, width, height):
+    out = np.zeros(12, np.float32)
+    _check(lib().ptmi_host_camera_frame(C.byref(cam), int(width), int(height), out.ctypes.data))
+    return out
+
+
+def host_local_row_map(height, n_ranks, rank, row_block):
+    t = Tiling(int(n_ranks), int(rank), int(row_block)); n = C.c_int()
+    _check(lib().ptmi_host_local_row_map(int(height), C.byref(t), C.byref(n), None))
+    rows = np.zeros(n.value, np.int32)
+    if n.value:
+        _check(lib().ptmi_host_local_row_map(int(height), C.byref(t), C.byref(n), rows.ctypes.data))
+    return rows
+
+
+def default_camera():
+    c = Camera(); lib().ptmi_default_camera(C.byref(c)); return c
+
+
+def default_config():
+    c = Config(); lib().ptmi_default_config(C.byref(c)); return c
+
+
+class Renderer:
+    """One ApplicationState bound to one GPU."""
+
+    def __init__(self, device_id=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self._ck(self.L.ptmi_ctx_create(int(device_id), C.byref(self.h)))
+        self.width = self.height = 0
+        self.config = default_config()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PtmiError(rc, self.L.ptmi_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.ptmi_ctx_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- SceneState::loadScene ---
+    def load_scene(self, filename, subdivision_count=0, convert_quads=False):
+        self._ck(self.L.ptmi_load_scene(self.h, os.fsencode(filename), int(subdivision_count), int(bool(convert_quads))))
+
+    def load_scene_arrays(self, types, verts, normal, bsdf, Le):
+        types = np.ascontiguousarray(types, np.int32)
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 4, 3)
+        normal, bsdf, Le = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (normal, bsdf, Le))
+        assert len(verts) == len(types) == len(normal) == len(bsdf) == len(Le)
+        self._ck(self.L.ptmi_load_scene_arrays(self.h, len(types), types.ctypes.data, verts.ctypes.data,
+                                               normal.ctypes.data, bsdf.ctypes.data, Le.ctypes.data))
+
+    def scene_info(self):
+        v = [C.c_int() for _ in range(5)]
+        self._ck(self.L.ptmi_scene_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_prims", "n_tris", "n_quads", "n_bvh_nodes", "bvh_depth"), (x.value for x in v)))
+
+    def scene_prims(self):
+        n = self.scene_info()["n_prims"]
+        t = np.zeros(n, np.int32); v = np.zeros((n, 4, 3), np.float32)
+        nr = np.zeros((n, 3), np.float32); b = np.zeros((n, 3), np.float32); le = np.zeros((n, 3), np.float32)
+        self._ck(self.L.ptmi_scene_get_prims(self.h, t.ctypes.data, v.ctypes.data, nr.ctypes.data, b.ctypes.data, le.ctypes.data))
+        return dict(type=t, verts=v, normal=nr, bsdf=b, Le=le)
+
+    def scene_bvh(self):
+        info = self.scene_info(); n, m = info["n_bvh_nodes"], info["n_prims"]
+        bmin = np.zeros((n, 3), np.float32); bmax = np.zeros((n, 3), np.float32)
+        left = np.zeros(n, np.int32); right = np.zeros(n, np.int32); count = np.zeros(n, np.int32); idx = np.zeros(m, np.int32)
+        self._ck(self.L.ptmi_scene_get_bvh(self.h, bmin.ctypes.data, bmax.ctypes.data, left.ctypes.data, right.ctypes.data,
+                                           count.ctypes.data, idx.ctypes.data))
+        return dict(bmin=bmin, bmax=bmax, left=left, right=right, count=count, indices=idx)
+
+    # --- RenderState::updateResolution / allocateBuffers ---
+    def update_resolution(self, width, height, n_ranks=1, rank=0, row_block=8):
+        t = Tiling(int(n_ranks), int(rank), int(row_block))
+        self._ck(self.L.ptmi_update_resolution(self.h, int(width), int(height), C.byref(t)))
+        self.width, self.height = int(width), int(height)
+
+    def set_camera(self, cam):
+        self._ck(self.L.ptmi_set_camera(self.h, C.byref(cam)))
+
+    def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None):
+        c = self.config
+        if spp is not None: c.spp = int(spp)
+        if max_depth is not None: c.max_depth = int(max_depth)
+        if seed_base is not None: c.seed_base = int(seed_base)
+        if segments_per_launch is not None: c.segments_per_launch = int(segments_per_launch)
+        if collect_stats is not None: c.collect_stats = int(bool(collect_stats))
+        self._ck(self.L.ptmi_set_config(self.h, C.byref(c)))
+
+    def camera_frame(self):
+        out = np.zeros(12, np.float32)
+        self._ck(self.L.ptmi_get_camera_frame(self.h, out.ctypes.data)); return out
+
+    def local_rows(self):
+        n = C.c_int(); self._ck(self.L.ptmi_local_rows(self.h, C.byref(n)))
+        rows = np.zeros(n.value, np.int32)
+        if n.value: self._ck(self.L.ptmi_local_row_map(self.h, rows.ctypes.data))
+        return rows
+
+    # --- renderFrame ---
+    def render_frame(self, want_stats=True):
+        st = Stats()
+        self._ck(self.L.ptmi_render_frame(self.h, C.byref(st) if want_stats else None))
+        return st
+
+    def device_image(self):
+        a = C.c_void_p(); b = C.c_void_p()
+        self._ck(self.L.ptmi_device_image(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def read_image(self, rgb8=True, radiance=True):
+        n = len(self.local_rows())
+        rgb = np.zeros((n, self.width, 3), np.uint8) if rgb8 else None
+        rad = np.zeros((n, self.width, 3), np.float32) if radiance else None
+        self._ck(self.L.ptmi_read_image(self.h, rgb.ctypes.data if rgb8 else None, rad.ctypes.data if radiance else None))
+        return rgb, rad
+
+    def copy_image_device(self, d_rgb8_ptr=None, d_radiance_ptr=None):
+        """D2D copy of the local rows into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr())."""
+        self._ck(self.L.ptmi_copy_image_device(self.h, d_rgb8_ptr, d_radiance_ptr))
+
+    # --- test hooks ---
+    def debug_intersect(self, o, d, t_min=1e-4, t_max=3.4028234663852886e38):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.int32); prim = np.zeros(n, np.int32); t = np.zeros(n, np.float32)
+        p = np.zeros((n, 3), np.float32); nr = np.zeros((n, 3), np.float32)
+        self._ck(self.L.ptmi_debug_intersect(self.h, n, o.ctypes.data, d.ctypes.data, t_min, t_max, hit.ctypes.data,
+                                             prim.ctypes.data, t.ctypes.data, p.ctypes.data, nr.ctypes.data))
+        return dict(hit=hit, prim=prim, t=t, p=p, n=nr)
+
+    def debug_rng(self, seed_base, pixels, count):
+        pixels = np.ascontiguousarray(pixels, np.int32)
+        out = np.zeros((len(pixels), count), np.float32)
+        self._ck(self.L.ptmi_debug_rng(self.h, int(seed_base), len(pixels), pixels.ctypes.data, int(count), out.ctypes.data))
+        return out
+
+    def debug_cosine_sample(self, normals, u, v):
+        normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        u = np.ascontiguousarray(u, np.float32); v = np.ascontiguousarray(v, np.float32)
+        out = np.zeros_like(normals)
+        self._ck(self.L.ptmi_debug_cosine_sample(self.h, len(u), normals.ctypes.data, u.ctypes.data, v.ctypes.data, out.ctypes.data))
+        return out
+
+
+def render_image(scene_path, width, height, spp, max_depth=5, camera=None, device_id=0, **cfg):
+    """Convenience: load + allocate + one frame; returns (rgb8, radiance, stats) of the full frame."""
+    r = Renderer(device_id)
+    r.load_scene(scene_path)
+    if camera is not None: r.set_camera(camera)
+    r.update_resolution(width, height)
+    r.set_config(spp=spp, max_depth=max_depth, **cfg)
+    st = r.render_frame()
+    rgb, rad = r.read_image()
+    r.close()
+    return rgb, rad, st

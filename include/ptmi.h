@@ -1,0 +1,175 @@
+/* ptmi.h — C ABI of libptmi.so, the MI355X-native drop-in for the per-pixel
+ * path-tracing render loop of USharma002/CUDA-PathTracer.
+ *
+ * The reference has no plugin/FFI layer; its hot path is reached through three
+ * host entry points that mutate one global ApplicationState `g_state`
+ * (include/application_state.h:299-308, defined src/main.cu:51):
+ *
+ *   SceneState::loadScene(filename, subdivision_count, convert_quads)
+ *                                   include/application_state.h:367-464
+ *   RenderState::allocateBuffers() / updateResolution(w, h)
+ *                                   include/application_state.h:91-129
+ *   renderFrame()                   include/application.h:157-216
+ *
+ * A `ptmi_ctx` is that ApplicationState bound to one GPU; each function below
+ * names the reference interface it replaces.  Plain pointers and sizes only;
+ * every function returns 0 on success or a negative PTMI_E_* code and never
+ * throws across the boundary; `ptmi_last_error()` gives the message of the
+ * last failure on the calling thread.  One host thread per ctx.
+ *
+ * There is NO CPU fallback behind this ABI: without a usable HIP device
+ * `ptmi_ctx_create` fails with PTMI_E_NO_DEVICE.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_OK            0
+#define PTMI_E_INVALID    -1   /* bad argument / state (message says which) */
+#define PTMI_E_IO         -2   /* scene file missing, unsupported extension, no primitives */
+#define PTMI_E_NO_DEVICE  -3   /* no HIP device / wrong architecture */
+#define PTMI_E_HIP        -4   /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define PTMI_E_NOMEM      -5   /* device or host allocation failed (reference: cudaMallocSafe throws, utils/cuda_utils.h:54-60) */
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+/* Camera = the Sensor constructor arguments plus its public yaw/pitch members
+ * (include/rendering/sensor.h:16-29, 84-86).  orbit = 1 reproduces renderFrame(),
+ * which calls updateCameraOrbit() before every launch (application.h:161,
+ * sensor.h:56-67): the origin is re-derived from yaw/pitch/radius, radius being
+ * |origin - lookat| of the constructor call.  orbit = 0 uses `origin` as is
+ * (Sensor::setPosition, sensor.h:69-72).  Defaults: AppConfig,
+ * application_state.h:285-286, and sensor.h:24-25. */
+typedef struct {
+    float origin[3];      /* (0.5, 3, 8.5) */
+    float lookat[3];      /* (0, 2.5, 0)   */
+    float vup[3];         /* (0, 1, 0)     */
+    float vfov_deg;       /* 40            */
+    float yaw_deg;        /* 90            */
+    float pitch_deg;      /* 0             */
+    int   orbit;          /* 1             */
+} ptmi_camera;
+
+/* AppConfig members the path reads (application_state.h:262-293) plus the two
+ * values the reference hard-codes: max_depth = 5 (integrator.h:389) and the RNG
+ * seed base 2023 (integrator.h:279). */
+typedef struct {
+    int      spp;             /* AppConfig::spp, default 1 (UI range 1-1000, ui_windows.h:84) */
+    int      max_depth;       /* 5 = reference behaviour */
+    int      sampling_mode;   /* SamplingMode (render_config.h:38-44); only 0 = SAMPLING_BSDF is built */
+    uint64_t seed_base;       /* 2023 */
+    /* scheduling knob, results are independent of it: ray segments each path
+     * advances per kernel launch before state returns to HBM and the active
+     * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default */
+    int      segments_per_launch;
+    int      collect_stats;   /* 1: also count rays / node visits / primitive tests (slower build of the kernel) */
+} ptmi_config;
+
+/* Framebuffer sharding (new in this implementation; the reference is single-GPU).
+ * Rows are dealt to ranks in blocks of `row_block` rows, round-robin:
+ * global row y belongs to rank (y / row_block) % n_ranks.  RNG streams are keyed
+ * by the GLOBAL pixel index (integrator.h:278-279), so the union of all ranks'
+ * rows is bit-identical to a single-GPU frame. */
+typedef struct {
+    int n_ranks;      /* 1 */
+    int rank;         /* 0 */
+    int row_block;    /* 8 */
+} ptmi_tiling;
+
+typedef struct {
+    double   seconds;          /* device time of the frame (HIP events around all launches) */
+    double   bounce_kernel_ms; /* summed duration of the dominant kernel (ptmi_bounce) */
+    uint64_t bounce_launches;
+    uint64_t samples;          /* local pixels * spp */
+    uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */
+} ptmi_stats;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* initializeApplication()'s device setup (application.h:92-148). device_id: HIP ordinal. */
+int  ptmi_ctx_create(int device_id, ptmi_ctx** out);
+void ptmi_ctx_destroy(ptmi_ctx*);                       /* SceneState::cleanup + buffer frees, application_state.h:466-490 */
+const char* ptmi_last_error(void);
+void ptmi_default_camera(ptmi_camera*);                 /* AppConfig() defaults */
+void ptmi_default_config(ptmi_config*);
+void ptmi_default_tiling(ptmi_tiling*);
+
+/* ---- SceneState::loadScene (application_state.h:367-464) ------------------ */
+/* Parses .obj/.mtl with the reference loader's rules (utils/file_manager.h:39-273),
+ * optionally converts quads to triangles (application_state.h:323-365) and
+ * subdivides (rendering/form_factors.h:475-574), builds the reference's BVH
+ * (rendering/bvh.h:76-219) and uploads an SoA copy.  Replaces any previous scene. */
+int ptmi_load_scene(ptmi_ctx*, const char* filename, int subdivision_count, int convert_quads);
+/* Same, from arrays (procedural scenes).  type[i]: 0 triangle, 1 quad; verts: n*4*3
+ * floats (4th vertex ignored for triangles); normal/bsdf/Le: n*3 floats. */
+int ptmi_load_scene_arrays(ptmi_ctx*, int n, const int* type, const float* verts,
+                           const float* normal, const float* bsdf, const float* Le);
+int ptmi_scene_info(const ptmi_ctx*, int* n_prims, int* n_tris, int* n_quads, int* n_bvh_nodes, int* bvh_depth);
+/* Host copies for inspection/tests; arrays sized from ptmi_scene_info. Any pointer may be NULL. */
+int ptmi_scene_get_prims(const ptmi_ctx*, int* type, float* verts, float* normal, float* bsdf, float* Le);
+int ptmi_scene_get_bvh(const ptmi_ctx*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
+
+/* ---- RenderState::allocateBuffers / updateResolution (application_state.h:91-129)
+ * (Re)allocates the image, path-state and RNG buffers for this rank's rows of a
+ * width x height frame and runs render_init (integrator.h:274-280), i.e. RNG
+ * streams are re-seeded on every call, as in the reference. */
+int ptmi_update_resolution(ptmi_ctx*, int width, int height, const ptmi_tiling* tiling /* NULL = single GPU */);
+int ptmi_set_camera(ptmi_ctx*, const ptmi_camera*);
+int ptmi_set_config(ptmi_ctx*, const ptmi_config*);
+/* Derived camera exactly as Sensor holds it after updateCameraOrbit()/updateCamera():
+ * origin, lower_left_corner, horizontal, vertical (12 floats). */
+int ptmi_get_camera_frame(const ptmi_ctx*, float* out12);
+int ptmi_local_rows(const ptmi_ctx*, int* n_rows);      /* rows of the frame this rank renders */
+/* global row index of each local row, n_rows ints */
+int ptmi_local_row_map(const ptmi_ctx*, int* rows_out);
+
+/* ---- renderFrame (application.h:157-216) ----------------------------------
+ * Renders config.spp samples for every local pixel (RNG state carries over
+ * from the previous frame, as in the reference) and leaves the results on the
+ * device.  Asynchronous work is complete when it returns. */
+int ptmi_render_frame(ptmi_ctx*, ptmi_stats* stats /* may be NULL */);
+
+/* Results.  Both images hold this rank's rows only, local row-major
+ * (local_rows x width x 3); local row r is global row ptmi_local_row_map()[r];
+ * row 0 of the frame is the BOTTOM row (v = y/H from the lower-left corner,
+ * integrator.h:384-385; the reference flips on PNG save, ui_windows.h:205).
+ * rgb8   : the reference's output (mean -> Reinhard -> gamma 2.2 -> 8 bit, integrator.h:393-407)
+ * radiance: mean linear radiance before tone mapping (float), an addition for parity checks. */
+int ptmi_device_image(const ptmi_ctx*, void** d_rgb8, void** d_radiance);           /* device pointers (for RCCL gathers) */
+int ptmi_read_image(const ptmi_ctx*, unsigned char* rgb8, float* radiance);          /* D2H of the local rows; either may be NULL */
+/* D2D copy of the local rows into caller-owned DEVICE buffers (e.g. the send buffers of an RCCL gather); either may be NULL */
+int ptmi_copy_image_device(const ptmi_ctx*, void* d_rgb8_dst, void* d_radiance_dst);
+
+/* ---- host-only halves (no device touched; usable without a GPU) ----------------
+ * The parse/convert/subdivide/BVH half of loadScene and the camera/tiling arithmetic, for
+ * inspection and for tests of the host logic. */
+typedef struct ptmi_host_scene ptmi_host_scene;
+int  ptmi_host_scene_load(const char* filename, int subdivision_count, int convert_quads, ptmi_host_scene** out);
+int  ptmi_host_scene_from_arrays(int n, const int* type, const float* verts, const float* normal,
+                                 const float* bsdf, const float* Le, ptmi_host_scene** out);
+void ptmi_host_scene_free(ptmi_host_scene*);
+int  ptmi_host_scene_info(const ptmi_host_scene*, int* n_prims, int* n_tris, int* n_quads, int* n_bvh_nodes, int* bvh_depth);
+int  ptmi_host_scene_get_prims(const ptmi_host_scene*, int* type, float* verts, float* normal, float* bsdf, float* Le);
+int  ptmi_host_scene_get_bvh(const ptmi_host_scene*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
+/* Sensor after allocateBuffers() + renderFrame()'s camera update for a width x height frame (12 floats). */
+int  ptmi_host_camera_frame(const ptmi_camera*, int width, int height, float* out12);
+/* rows of a `height`-row frame owned by `tiling->rank`; rows_out may be NULL to query the count only */
+int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows, int* rows_out);
+
+/* ---- unit-test hooks: single stages of the path on the device ------------- */
+/* Scene::intersect (scene.h:39-110) for n rays given as-is (no normalisation). out_*: n each; p/nrm 3n. */
+int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
+                         int* hit, int* prim, float* t, float* p, float* nrm);
+/* render_init + curand_uniform: first `count` uniforms of pixel stream (seed_base+pixel, subsequence pixel). */
+int ptmi_debug_rng(ptmi_ctx*, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out /* n_pixels*count */);
+/* sampleCosineHemisphere (integrator.h:62-85) with explicit (u, v). */
+int ptmi_debug_cosine_sample(ptmi_ctx*, int n, const float* normals, const float* u, const float* v, float* out_dirs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

@@ -1,0 +1,139 @@
+"""CPU-only tests of the PRODUCT's host half (libptmi.so through the C ABI): the C++ loader, quad
+conversion, subdivision, BVH builder, camera and tiling arithmetic must agree bit-for-bit with the
+oracle (an independent plain-C restatement).  No GPU is touched; no render call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ptmi
+from oracle_binding import OracleScene, SCENES, Camera as OCamera, camera_frame, default_camera
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, F).view(np.uint32)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = ptmi.lib()
+    header = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    declared = set(re.findall(r"\b(ptmi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ptmi_tiling"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libptmi.so does not export {name}"
+    assert declared == set(ptmi.EXPORTS), declared ^ set(ptmi.EXPORTS)
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ptmi.PtmiError) as e:
+        ptmi.Renderer(0)
+    assert e.value.code == -3
+
+
+VARIANTS = [("cbox.obj", 0, False), ("cbox_quads.obj", 0, False), ("cbox_quads.obj", 0, True), ("cbox.obj", 1, False),
+            ("cbox.obj", 2, False), ("cbox_quads.obj", 1, False), ("cbox_quads.obj", 2, True), ("cbox_quads.obj", 3, False)]
+
+
+@pytest.mark.parametrize("name,sub,conv", VARIANTS)
+def test_loader_and_bvh_match_oracle(name, sub, conv):
+    path = os.path.join(SCENES, name)
+    h = ptmi.HostScene.load(path, sub, conv)
+    o = OracleScene.load(path, sub, conv)
+    hp, op = h.prims(), o.prims()
+    assert h.info()["n_prims"] == o.n_prims and h.info()["n_bvh_nodes"] == o.n_nodes
+    assert (hp["type"] == op["type"]).all()
+    tri = hp["type"] == 0
+    assert (bits(hp["verts"][tri][:, :3]) == bits(op["verts"][tri][:, :3])).all()
+    assert (bits(hp["verts"][~tri]) == bits(op["verts"][~tri])).all()
+    for k in ("normal", "bsdf", "Le"):
+        assert (bits(hp[k]) == bits(op[k])).all(), k
+    hb, ob = h.bvh(), o.bvh()
+    for k in ("left", "count", "indices"):
+        assert (hb[k] == ob[k]).all(), k
+    inner = hb["count"] == 0
+    assert (hb["right"][inner] == ob["right"][inner]).all()
+    assert (bits(hb["bmin"]) == bits(ob["bmin"])).all() and (bits(hb["bmax"]) == bits(ob["bmax"])).all()
+
+
+def test_arrays_scene_and_degenerate_bvh():
+    rng = np.random.default_rng(3)
+    n = 3000
+    types = (rng.random(n) < 0.4).astype(np.int32)
+    verts = (rng.uniform(-5, 5, (n, 1, 3)) + rng.normal(0, 0.3, (n, 4, 3))).astype(F)
+    normal = rng.normal(0, 1, (n, 3)).astype(F); bsdf = rng.random((n, 3)).astype(F); Le = np.zeros((n, 3), F)
+    # a clump of identical primitives forces the "centroid extent < 1e-6" oversized leaf
+    verts[100:120] = verts[100]; types[100:120] = types[100]
+    h = ptmi.HostScene.from_arrays(types, verts, normal, bsdf, Le)
+    o = OracleScene.from_arrays(types, verts, normal, bsdf, Le)
+    hb, ob = h.bvh(), o.bvh()
+    assert len(hb["left"]) == len(ob["left"])
+    for k in ("left", "count", "indices"):
+        assert (hb[k] == ob[k]).all(), k
+    assert (bits(hb["bmin"]) == bits(ob["bmin"])).all()
+    assert hb["count"].max() > 4
+    assert h.info()["bvh_depth"] >= 8
+
+
+def test_loader_error_behaviour(tmp_path):
+    with pytest.raises(ptmi.PtmiError) as e:
+        ptmi.HostScene.load(str(tmp_path / "missing.obj"))
+    assert e.value.code == -2
+    p = tmp_path / "scene.ply"; p.write_text("ply\n")
+    with pytest.raises(ptmi.PtmiError) as e:
+        ptmi.HostScene.load(str(p))
+    assert e.value.code == -2 and "unsupported" in str(e.value)
+    p = tmp_path / "empty.obj"; p.write_text("# nothing\nv 0 0 0\n")
+    with pytest.raises(ptmi.PtmiError):
+        ptmi.HostScene.load(str(p))
+
+
+def test_loader_quirks(tmp_path):
+    """Ragged input the reference loader tolerates (file_manager.h:118-250)."""
+    (tmp_path / "m.mtl").write_text("newmtl A\nKd 0.1 0.2 0.3\nKe 1 2 3\nKs 9 9 9\n\nnewmtl B\n  Kd 0.5 0.5 0.5\n")
+    obj = tmp_path / "q.OBJ"          # extension check is case-insensitive
+    obj.write_text("\n".join([
+        "mtllib m.mtl", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0 0 1", "vn 0 0 2", "vt 0.5 0.5",
+        "object_line_is_skipped_because_it_starts_with_o", "s off",
+        "usemtl A", "f 1/1/1 2/1/1 3/1/1", "f 1//1 2//1 3//1 4//1   # trailing comment tokens are skipped",
+        "usemtl NOPE", "f 1 2 5", "f 1 2", "f 1 2 3 4 5", "f 1 2 99", "f -1 2 3", "usemtl B", "f 1/7 2/7 3/7", ""]))
+    h = ptmi.HostScene.load(str(obj)); o = OracleScene.load(str(obj))
+    hp, op = h.prims(), o.prims()
+    assert hp["type"].tolist() == [0, 1, 0, 0] == op["type"].tolist()
+    assert np.allclose(hp["normal"][0], [0, 0, 1]) and np.allclose(hp["Le"][0], [1, 2, 3]) and np.allclose(hp["bsdf"][0], [0.1, 0.2, 0.3])
+    assert np.allclose(hp["bsdf"][2], [0.8, 0.8, 0.8]) and np.allclose(hp["Le"][2], 0)      # unknown material -> default
+    assert np.allclose(hp["bsdf"][3], [0.5, 0.5, 0.5])
+    for k in ("normal", "bsdf", "Le"):
+        assert (bits(hp[k]) == bits(op[k])).all()
+
+
+def test_camera_frame_matches_oracle():
+    cams = [ptmi.default_camera(),
+            ptmi.Camera((0.5, 3.0, 8.5), (0, 2.5, 0), (0, 1, 0), 40.0, 37.5, -12.25, 1),
+            ptmi.Camera((1.0, 2.0, 7.0), (0.2, 2.5, -1), (0, 1, 0), 30.0, 90.0, 0.0, 0),
+            ptmi.Camera((-2.0, 4.0, 3.0), (0, 2.5, -3), (0.1, 1, 0), 70.0, 200.0, -45.0, 1)]
+    for cam in cams:
+        ocam = OCamera(tuple(cam.origin), tuple(cam.lookat), tuple(cam.vup), cam.vfov_deg, cam.yaw_deg, cam.pitch_deg, cam.orbit)
+        for (w, hgt) in ((1024, 1024), (1920, 1080), (200, 333)):
+            assert (bits(ptmi.host_camera_frame(cam, w, hgt)) == bits(camera_frame(ocam, w, hgt).as_array())).all()
+
+
+def test_tiling_partitions_rows_exactly_once():
+    for height in (1, 7, 64, 1080, 1448):
+        for n_ranks in (1, 2, 3, 4, 8):
+            for row_block in (1, 4, 8, 16):
+                seen = np.concatenate([ptmi.host_local_row_map(height, n_ranks, r, row_block) for r in range(n_ranks)])
+                assert sorted(seen.tolist()) == list(range(height))
+                for r in range(n_ranks):
+                    rows = ptmi.host_local_row_map(height, n_ranks, r, row_block)
+                    assert ((rows // row_block) % n_ranks == r).all() and (np.diff(rows) > 0).all()
+    with pytest.raises(ptmi.PtmiError):
+        ptmi.host_local_row_map(16, 2, 2, 8)
