@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the per-pixel render loop on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one renderFrame(): all spp samples of every pixel of the frame (scene, path state and RNG
+streams resident in HBM; successive steps are successive frames, RNG state carrying over as in the reference).
+
+N = 1 : BASELINE.json configs[1] — cbox.obj, 1024x1024, 256 spp, max 8 bounces.
+N > 1 : weak scaling — the same view and spp at side = round(1024*sqrt(N)) pixels, so every GPU owns
+        ~1024^2 pixels; rows are dealt to ranks in interleaved 8-row blocks (no data-path collective),
+        and ONE RCCL gather over xGMI at frame end brings the tiles to rank 0 (inside the timed region).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel ptmi_bounce, HIP-event timed inside the
+library on its own stream) and `cpu_baseline` (the oracle, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ptmi  # noqa: E402
+
+SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
+SPP, MAX_DEPTH, BASE_SIDE, ROW_BLOCK = 256, 8, 1024, 8
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_sample(st, quads):
+    """rays/sample * (144 + 32*nodes/ray + 36|48*tests/ray + 36*hit_rate) + 24."""
+    rays_per_sample = st.rays / st.samples
+    return rays_per_sample * (144.0 + 32.0 * st.node_visits / st.rays + (48.0 if quads else 36.0) * st.prim_tests / st.rays
+                              + 36.0 * st.hits / st.rays) + 24.0
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, math.ceil(q / per)))
+            break
+        except Exception:
+            continue
+    return cores
+
+
+def cpu_baseline(side, target_seconds=12.0):
+    """The oracle (CPU restatement, kind "port") on all host cores, same scene/camera/depth, reduced spp."""
+    from oracle_binding import OracleScene, default_camera
+    o = OracleScene.load(SCENE)
+    cores = host_cores()
+    _, _, st = o.render(default_camera(), side, side, 2, max_depth=MAX_DEPTH, n_threads=cores)      # calibrate
+    rate = st.samples / max(st.seconds, 1e-9)
+    spp = int(max(2, min(SPP, round(target_seconds * rate / (side * side)))))
+    _, _, st = o.render(default_camera(), side, side, spp, max_depth=MAX_DEPTH, n_threads=cores)
+    return {"value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"cbox.obj {side}x{side}, {spp} of {SPP} spp, max_depth {MAX_DEPTH}, "
+                      f"{st.samples / 1e6:.1f} Msamples in {st.seconds:.1f} s (oracle/ptmi_oracle.c, OpenMP over rows)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)          # for quick experiments only
+    ap.add_argument("--side", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world != n_gpus:
+        if world == 1 and n_gpus > 1:
+            raise SystemExit(f"--gpus {n_gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr 127.0.0.1 bench.py ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {n_gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    side = args.side or int(round(BASE_SIDE * math.sqrt(n_gpus)))
+    spp = args.spp
+
+    r = ptmi.Renderer(local_rank)
+    r.load_scene(SCENE)
+    quads = r.scene_info()["n_quads"] > 0
+
+    def allocate():
+        r.update_resolution(side, side, n_ranks=world, rank=rank, row_block=ROW_BLOCK)   # re-seeds the RNG streams
+
+    allocate()
+    rows = r.local_rows()
+    n_local_rows = len(rows)
+    max_rows = int(max(len(ptmi.host_local_row_map(side, world, k, ROW_BLOCK)) for k in range(world)))
+
+    # gather plumbing (torch = device memory + RCCL only)
+    dev = torch.device("cuda", local_rank)
+    send_rad = torch.zeros((max_rows, side, 3), dtype=torch.float32, device=dev)
+    send_rgb = torch.zeros((max_rows, side, 3), dtype=torch.uint8, device=dev)
+    if world > 1 and rank == 0:
+        recv_rad = [torch.empty_like(send_rad) for _ in range(world)]
+        recv_rgb = [torch.empty_like(send_rgb) for _ in range(world)]
+        row_maps = [torch.from_numpy(ptmi.host_local_row_map(side, world, k, ROW_BLOCK).astype(np.int64)).to(dev) for k in range(world)]
+        frame_rad = torch.empty((side, side, 3), dtype=torch.float32, device=dev)
+        frame_rgb = torch.empty((side, side, 3), dtype=torch.uint8, device=dev)
+
+    def step(stats):
+        st = r.render_frame(want_stats=stats)
+        if world > 1:
+            r.copy_image_device(send_rgb.data_ptr(), send_rad.data_ptr())
+            dist.gather(send_rad, recv_rad if rank == 0 else None, dst=0)
+            dist.gather(send_rgb, recv_rgb if rank == 0 else None, dst=0)
+            if rank == 0:
+                for k in range(world):
+                    m = row_maps[k]
+                    frame_rad[m] = recv_rad[k][: len(m)]
+                    frame_rgb[m] = recv_rgb[k][: len(m)]
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: deterministic workload counters for the roofline model (stats build of the kernel)
+    r.set_config(spp=spp, max_depth=MAX_DEPTH, segments_per_launch=args.segments, collect_stats=True)
+    st_counts = r.render_frame()
+    bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
+
+    # Successive steps are successive frames: as in the reference, the RNG streams carry over from frame to
+    # frame (integrator.h:379), so every step is statistically the same work on fresh samples.
+    r.set_config(collect_stats=False)
+    for _ in range(args.warmup):
+        step(False)
+
+    kernel_ms = 0.0
+    launches = 0
+    frame_dev_s = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step(True)
+        kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; frame_dev_s += st.seconds
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(side) * side * spp * args.steps
+    value = total_samples / elapsed / 1e6
+    # roofline of the dominant kernel on THIS rank: algorithmic bytes of its launches / their summed duration
+    local_samples = float(n_local_rows) * side * spp * args.steps
+    achieved = local_samples * bytes_per_sample / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_bounce.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cbox.obj {side}x{side}, {spp} spp, max_depth {MAX_DEPTH}, Cornell-box scene fixture, "
+                                   f"default camera, seed 2023" + ("" if world == 1 else f", {world} GPUs x ~{BASE_SIDE}^2 px, interleaved {ROW_BLOCK}-row blocks + 1 RCCL gather"),
+                       "width": side, "height": side, "spp": spp, "max_depth": MAX_DEPTH,
+                       "segments_per_launch": args.segments or "default", "parallelism": f"tile{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "ptmi_bounce", "launches_per_step": launches / max(args.steps, 1),
+                         "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+                         "algorithmic_bytes_per_launch": round(local_samples * bytes_per_sample / max(launches, 1), 1),
+                         "kernel_share_of_frame": round(kernel_ms * 1e-3 / max(frame_dev_s, 1e-12), 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(side)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
