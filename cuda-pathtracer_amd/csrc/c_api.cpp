@@ -316,6 +316,18 @@ int ptmi_copy_image_device(const ptmi_ctx* c, void* d_rgb8_dst, void* d_radiance
     });
 }
 
+int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, int* out_mode) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(force_mode >= -1 && force_mode <= 2, "force_mode must be -1..2");
+        need(sweep_max_prims >= 0, "sweep_max_prims must be >= 0");
+        SceneState& s = c->app.scene;
+        s.force_traversal = force_mode; s.sweep_max_prims = sweep_max_prims;
+        s.chooseTraversal();
+        if (out_mode) *out_mode = s.d_nodes ? s.d_scene.traversal : -1;
+    });
+}
+
 int ptmi_debug_intersect(ptmi_ctx* c, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm) {
     return guarded([&] {

@@ -4,8 +4,11 @@
 // reads/writes 1 KiB per instruction (global_load_dwordx4, ds_read_b128).
 //
 // SCENE (read-only, replicated on every GPU; staged into LDS when it fits)
-//   nodes[2*i+0] = (bbox.min.xyz, bits(left))      left : inner -> left child, leaf -> first primitive slot
-//   nodes[2*i+1] = (bbox.max.xyz, bits(right))     right: inner -> right child (>0), leaf -> -prim_count (<0)
+//   nodes[2*i+0] = (bbox.min.xyz, bits(a))         a: inner -> SKIP index (first node after this subtree in pre-order),
+//                                                     leaf  -> first primitive slot
+//   nodes[2*i+1] = (bbox.max.xyz, bits(b))         b: inner -> right child (>0), leaf -> -prim_count (<0)
+//   Nodes are numbered in pre-order (bvh.h:154-218), so an inner node's left child is always i+1 and the
+//   reference's "push right, push left, pop" order (scene.h:101-105) is exactly "i+1 if the box is hit, else skip".
 //   prims[S*k+0] = (v0.xyz, bits(type))            k = LEAF-ORDER slot (reference's bvh_indices applied on the host,
 //   prims[S*k+1] = (v1-v0 | v10-v00, 0)              so a leaf's primitives are contiguous); S = 3 for triangle-only
 //   prims[S*k+2] = (v2-v0 | v11-v00, 0)              scenes, 4 when quads are present.  Edges are precomputed with the
@@ -37,8 +40,17 @@ struct DeviceScene {
     int n_nodes = 0, n_prims = 0;
     int prim_stride = 3;      // float4 per primitive
     int has_quads = 0;
-    int stack_entries = 1;    // min(bvh depth + 1, 64)
-    int lds_resident = 0;     // 1: nodes+prims+mats are staged into LDS by every workgroup
+    int stack_entries = 1;    // min(bvh depth + 1, 64); only the STACK traversal uses it
+    int lds_resident = 0;     // 1: nodes+prims+mats are staged into LDS by every workgroup (LANE/STACK traversal)
+    int traversal = 1;        // TraversalMode
+};
+
+// How ptmi_bounce walks the BVH.  All three visit the same nodes and primitives in the same order per ray.
+enum TraversalMode {
+    TRAVERSAL_SWEEP = 0,   // tiny scenes: the WAVE walks node indices 0..N-1 once, node/primitive data are wave-uniform
+                           // scalar loads (SGPR operands), lanes whose own cursor equals the index take part
+    TRAVERSAL_LANE = 1,    // general: every lane walks its own pre-order cursor (stackless, skip pointers)
+    TRAVERSAL_STACK = 2,   // trees deeper than 62: explicit LDS stack with the reference's drop rule (scene.h:101-105)
 };
 
 struct PathState {

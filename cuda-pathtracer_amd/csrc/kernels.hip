@@ -167,19 +167,59 @@ __device__ __forceinline__ f3 xyz(const float4& v) { return mk3(v.x, v.y, v.z); 
 
 struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits; };
 
-// Scene::intersect_bvh_optimized (scene.h:50-110).  `stack` points at this lane's column of the LDS stack
-// (entry e lives at stack[e * kBlock]).  The node about to be visited is kept in a register instead of being
-// pushed and popped again; the reference's "drop both children when stack_ptr >= 62" rule (scene.h:101-105)
-// is evaluated on the same stack_ptr value the reference would see.
+// Slab test of scene.h:66-81 against [t_min, closest_t]; returns false when the reference would `continue`.
+__device__ __forceinline__ bool box_hit(const float4& n0, const float4& n1, f3 o, f3 inv, float t_min, float closest_t) {
+    float tmin_box = t_min, tmax_box = closest_t;
+    {
+        float t0 = (n0.x - o.x) * inv.x, t1 = (n1.x - o.x) * inv.x;
+        if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+    }
+    {
+        float t0 = (n0.y - o.y) * inv.y, t1 = (n1.y - o.y) * inv.y;
+        if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+    }
+    {
+        float t0 = (n0.z - o.z) * inv.z, t1 = (n1.z - o.z) * inv.z;
+        if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+    }
+    return !(tmax_box < tmin_box);
+}
+
+// Primitive::intersect (primitive.h:83-90) + the closer-hit update of scene.h:89-96 for leaf slot k.
+template <bool HAS_QUADS>
+__device__ __forceinline__ void leaf_prim(const float4* __restrict__ prims, int prim_stride, int k, f3 o, f3 d, float t_min,
+                                          float& closest_t, int& slot_hit, bool& hit_anything) {
+    const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+    float t;
+    bool h;
+    if (HAS_QUADS && __float_as_int(p0.w) != 0) {
+        const float4 p3 = prims[k * prim_stride + 3];
+        float c = closest_t;                                                  // Quad::intersect starts from t_max = closest_t
+        h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);             // (v00, v10, v11)
+        h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;        // (v00, v11, v01)
+        t = c;
+    } else {
+        h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
+    }
+    if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }
+}
+
+// ---- TRAVERSAL_STACK: Scene::intersect_bvh_optimized (scene.h:50-110) with its explicit stack ------------------
+// `stack` points at this lane's column of the LDS stack (entry e lives at stack[e * kBlock]).  The node about to be
+// visited is kept in a register instead of being pushed and popped again; the reference's "drop both children when
+// stack_ptr >= 62" rule (scene.h:101-105) is evaluated on the same stack_ptr value the reference would see.
 template <bool HAS_QUADS, bool STATS>
-__device__ __forceinline__ bool scene_intersect(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
-                                                int* stack, f3 o, f3 d, float t_min, float t_max,
+__device__ __forceinline__ bool intersect_stack(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
+                                                int* stack, bool live, f3 o, f3 d, float t_min, float t_max,
                                                 float& t_hit, int& slot_hit, LaneCounters& cn) {
     bool hit_anything = false;
     float closest_t = t_max;
     const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
     int sp = 0;
-    int cur = 0;
+    int cur = live ? 0 : -1;
     while (true) {
         if (cur < 0) {
             if (sp == 0) break;
@@ -187,51 +227,134 @@ __device__ __forceinline__ bool scene_intersect(const float4* __restrict__ nodes
         }
         const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
         if (STATS) cn.node_visits++;
+        const int here = cur;
         cur = -1;
-        float tmin_box = t_min, tmax_box = closest_t;
-        {
-            float t0 = (n0.x - o.x) * inv.x, t1 = (n1.x - o.x) * inv.x;
-            if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
-        }
-        {
-            float t0 = (n0.y - o.y) * inv.y, t1 = (n1.y - o.y) * inv.y;
-            if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
-        }
-        {
-            float t0 = (n0.z - o.z) * inv.z, t1 = (n1.z - o.z) * inv.z;
-            if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-            tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
-        }
-        if (tmax_box < tmin_box) continue;
-        const int left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-        if (right < 0) {                                   // leaf: -right primitives from slot `left`
-            const int count = -right;
-            for (int i = 0; i < count; i++) {
-                const int k = left + i;
-                const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+        if (!box_hit(n0, n1, o, inv, t_min, closest_t)) continue;
+        const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+        if (b < 0) {                                       // leaf: -b primitives from slot a
+            for (int i = 0; i < -b; i++) {
                 if (STATS) cn.prim_tests++;
-                float t;
-                bool h;
-                if (HAS_QUADS && __float_as_int(p0.w) != 0) {
-                    const float4 p3 = prims[k * prim_stride + 3];
-                    float c = closest_t;                    // Quad::intersect starts from t_max = closest_t
-                    h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);           // (v00, v10, v11)
-                    h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;      // (v00, v11, v01)
-                    t = c;
-                } else {
-                    h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
-                }
-                if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }   // scene.h:89-96
+                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
             }
-        } else if (sp < 62) {                              // push right, visit left next (scene.h:101-105)
-            stack[(sp++) * kBlock] = right;
-            cur = left;
+        } else if (sp < 62) {                              // push right, visit left (= here + 1) next
+            stack[(sp++) * kBlock] = b;
+            cur = here + 1;
         }
     }
     t_hit = closest_t;
     return hit_anything;
+}
+
+// ---- TRAVERSAL_LANE: the same walk without a stack ---------------------------------------------------------------
+// Pre-order numbering makes "pop" a table lookup: after a node whose box is missed the next node is its skip index,
+// otherwise it is index + 1.  Valid while the reference's stack never overflows (tree depth <= 62).
+template <bool HAS_QUADS, bool STATS>
+__device__ __forceinline__ bool intersect_lane(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
+                                               int n_nodes, bool live, f3 o, f3 d, float t_min, float t_max,
+                                               float& t_hit, int& slot_hit, LaneCounters& cn) {
+    bool hit_anything = false;
+    float closest_t = t_max;
+    const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    int cur = live ? 0 : n_nodes;
+    while (cur < n_nodes) {
+        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+        if (STATS) cn.node_visits++;
+        const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+        const bool pass = box_hit(n0, n1, o, inv, t_min, closest_t);
+        int next = cur + 1;
+        if (!pass && b >= 0) next = a;
+        if (pass && b < 0) {
+            for (int i = 0; i < -b; i++) {
+                if (STATS) cn.prim_tests++;
+                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
+            }
+        }
+        cur = next;
+    }
+    t_hit = closest_t;
+    return hit_anything;
+}
+
+// ---- TRAVERSAL_SWEEP: the WAVE walks the node indices once -----------------------------------------------------
+// Every lane's cursor only moves forward through the pre-order, so one pass n = 0..N-1 with "lanes whose cursor == n
+// take part" visits, per lane, exactly the nodes and primitives of the walks above, in the same order.  n is
+// wave-uniform: node and primitive records come in through scalar loads (s_load_dwordx4 -> SGPR operands), there is
+// no stack, no per-lane LDS read, and lanes at different depths of the tree never serialise against each other.
+// The wave pays for the UNION of its lanes' visits, so this is used only for scenes of a few dozen primitives.
+// Must be called from wave-uniform control flow (dead lanes pass live = false).
+// Scene arrays viewed through the CONSTANT address space: with a wave-uniform index the compiler then emits
+// s_load_dwordx4 (scalar cache, SGPR destination) instead of a per-lane global_load.  Legal because no kernel
+// ever writes the scene.
+typedef const __attribute__((address_space(4))) float* const_f_ptr;
+struct const_f4_ptr {                                   // float4 array seen as scalars (keeps the host pass happy)
+    const_f_ptr p;
+    __device__ __forceinline__ float4 operator[](int i) const { return make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }
+};
+__device__ __forceinline__ const_f4_ptr as_constant(const float4* p) {
+    const_f4_ptr r;
+    r.p = (const_f_ptr)(const __attribute__((address_space(1))) float*)reinterpret_cast<const float*>(p);
+    return r;
+}
+
+template <bool HAS_QUADS>
+__device__ __forceinline__ void leaf_prim_uniform(const_f4_ptr prims, int prim_stride, int k, f3 o, f3 d, float t_min,
+                                                  float& closest_t, int& slot_hit, bool& hit_anything) {
+    const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+    float t;
+    bool h;
+    if (HAS_QUADS && __float_as_int(p0.w) != 0) {                              // wave-uniform branch
+        const float4 p3 = prims[k * prim_stride + 3];
+        float c = closest_t;
+        h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);
+        h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;
+        t = c;
+    } else {
+        h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
+    }
+    if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }
+}
+
+template <bool HAS_QUADS, bool STATS>
+__device__ __forceinline__ bool intersect_sweep(const float4* __restrict__ nodes_g, const float4* __restrict__ prims_g, int prim_stride,
+                                                int n_nodes, bool live, f3 o, f3 d, float t_min, float t_max,
+                                                float& t_hit, int& slot_hit, LaneCounters& cn) {
+    const const_f4_ptr nodes = as_constant(nodes_g), prims = as_constant(prims_g);
+    bool hit_anything = false;
+    float closest_t = t_max;
+    const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    int cur = live ? 0 : n_nodes;
+    for (int n = 0; n < n_nodes; n++) {
+        if (cur == n) {
+            // readfirstlane pins the index to an SGPR: inside this branch the optimiser knows cur == n and would
+            // otherwise address the node through the per-lane cursor (vector loads)
+            const int nu = __builtin_amdgcn_readfirstlane(n);
+            const float4 n0 = nodes[2 * nu], n1 = nodes[2 * nu + 1];
+            if (STATS) cn.node_visits++;
+            const int a = __builtin_amdgcn_readfirstlane(__float_as_int(n0.w));
+            const int b = __builtin_amdgcn_readfirstlane(__float_as_int(n1.w));   // wave-uniform
+            const bool pass = box_hit(n0, n1, o, inv, t_min, closest_t);
+            cur = n + 1;
+            if (b < 0) {
+                if (pass) {
+                    for (int i = 0; i < -b; i++) {
+                        if (STATS) cn.prim_tests++;
+                        leaf_prim_uniform<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
+                    }
+                }
+            } else if (!pass) cur = a;
+        }
+    }
+    t_hit = closest_t;
+    return hit_anything;
+}
+
+template <int MODE, bool HAS_QUADS, bool STATS>
+__device__ __forceinline__ bool scene_intersect(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
+                                                int n_nodes, int* stack, bool live, f3 o, f3 d, float t_min, float t_max,
+                                                float& t_hit, int& slot_hit, LaneCounters& cn) {
+    if (MODE == TRAVERSAL_SWEEP) return intersect_sweep<HAS_QUADS, STATS>(nodes, prims, prim_stride, n_nodes, live, o, d, t_min, t_max, t_hit, slot_hit, cn);
+    if (MODE == TRAVERSAL_LANE) return intersect_lane<HAS_QUADS, STATS>(nodes, prims, prim_stride, n_nodes, live, o, d, t_min, t_max, t_hit, slot_hit, cn);
+    return intersect_stack<HAS_QUADS, STATS>(nodes, prims, prim_stride, stack, live, o, d, t_min, t_max, t_hit, slot_hit, cn);
 }
 
 // sampleCosineHemisphere (integrator.h:62-85) with the two uniforms already drawn
@@ -267,24 +390,27 @@ struct BounceArgs {
     StatCounters* stats;
 };
 
-template <bool LDS_SCENE, bool HAS_QUADS, bool STATS>
+// LDS: [nodes | prims] when LDS_GEOM, [mats] when LDS_GEOM or MODE == SWEEP, then the traversal stacks (STACK only).
+template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
 __global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
-    // LDS: [nodes | prims | mats] (only when LDS_SCENE) then the per-lane traversal stacks
+    constexpr bool LDS_MATS = LDS_GEOM || MODE == TRAVERSAL_SWEEP;
     const int n_node_vec = 2 * a.sc.n_nodes, n_prim_vec = a.sc.prim_stride * a.sc.n_prims, n_mat_vec = 3 * a.sc.n_prims;
-    const float4* nodes = a.sc.nodes; const float4* prims = a.sc.prims; const float4* mats = a.sc.mats;
-    int* stack_base;
-    if (LDS_SCENE) {
-        for (int i = threadIdx.x; i < n_node_vec; i += kBlock) smem[i] = a.sc.nodes[i];
-        for (int i = threadIdx.x; i < n_prim_vec; i += kBlock) smem[n_node_vec + i] = a.sc.prims[i];
-        for (int i = threadIdx.x; i < n_mat_vec; i += kBlock) smem[n_node_vec + n_prim_vec + i] = a.sc.mats[i];
-        nodes = smem; prims = smem + n_node_vec; mats = smem + n_node_vec + n_prim_vec;
-        stack_base = reinterpret_cast<int*>(smem + n_node_vec + n_prim_vec + n_mat_vec);
-        __syncthreads();
-    } else {
-        stack_base = reinterpret_cast<int*>(smem);
+    const float4* __restrict__ nodes = a.sc.nodes; const float4* __restrict__ prims = a.sc.prims; const float4* mats = a.sc.mats;
+    float4* lds = smem;
+    if (LDS_GEOM) {
+        for (int i = threadIdx.x; i < n_node_vec; i += kBlock) lds[i] = a.sc.nodes[i];
+        for (int i = threadIdx.x; i < n_prim_vec; i += kBlock) lds[n_node_vec + i] = a.sc.prims[i];
+        nodes = lds; prims = lds + n_node_vec;
+        lds += n_node_vec + n_prim_vec;
     }
-    int* stack = stack_base + threadIdx.x;
+    if (LDS_MATS) {
+        for (int i = threadIdx.x; i < n_mat_vec; i += kBlock) lds[i] = a.sc.mats[i];
+        mats = lds;
+        lds += n_mat_vec;
+    }
+    if (LDS_GEOM || LDS_MATS) __syncthreads();
+    int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool active = idx < a.n_in;
@@ -310,10 +436,12 @@ __global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
 
     for (int seg = 0; seg < a.segments; seg++) {
         if (!__any(alive)) break;
+        // the whole wave enters the traversal together (finished lanes ride along masked): required by SWEEP
+        float t = 0.0f; int k = -1;
+        if (STATS && alive) cn.rays++;
+        const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
+                                                               o, d, 1e-4f, FLT_MAX, t, k, cn);
         if (alive) {
-            float t; int k = -1;
-            if (STATS) cn.rays++;
-            const bool hit = scene_intersect<HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, stack, o, d, 1e-4f, FLT_MAX, t, k, cn);
             bool end_sample = !hit;                                                   // integrator.h:198-201
             if (hit) {
                 if (STATS) cn.hits++;
@@ -385,20 +513,20 @@ __global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
 }
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
-    size_t b = (size_t)sc.stack_entries * kBlock * sizeof(int);
-    if (sc.lds_resident) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);
+    size_t b = 0;
+    const bool geom = sc.lds_resident && sc.traversal != TRAVERSAL_SWEEP;
+    if (geom) b += (size_t)(2 * sc.n_nodes + sc.prim_stride * sc.n_prims) * sizeof(float4);
+    if (geom || sc.traversal == TRAVERSAL_SWEEP) b += (size_t)3 * sc.n_prims * sizeof(float4);
+    if (sc.traversal == TRAVERSAL_STACK) b += (size_t)sc.stack_entries * kBlock * sizeof(int);
     return b;
 }
 
-void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
-                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
-                   StatCounters* stats, hipStream_t s) {
-    if (n_in <= 0) return;
-    BounceArgs a{sc, tm, st, fp, queue_in, n_in, queue_out, count_out, segments, stats};
-    const dim3 grid((n_in + kBlock - 1) / kBlock), block(kBlock);
-    const size_t lds = bounce_lds_bytes(sc);
-#define PTMI_LAUNCH(L_, Q_, S_) hipLaunchKernelGGL((ptmi_bounce<L_, Q_, S_>), grid, block, lds, s, a)
-    const int key = (sc.lds_resident ? 4 : 0) | (sc.has_quads ? 2 : 0) | (stats ? 1 : 0);
+template <int MODE>
+static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    const bool geom = a.sc.lds_resident && MODE != TRAVERSAL_SWEEP;
+    const int key = (geom ? 4 : 0) | (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
+    const dim3 block(kBlock);
+#define PTMI_LAUNCH(G_, Q_, S_) hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_>), grid, block, lds, s, a)
     switch (key) {
         case 0: PTMI_LAUNCH(false, false, false); break;
         case 1: PTMI_LAUNCH(false, false, true); break;
@@ -410,6 +538,18 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
         default: PTMI_LAUNCH(true, true, true); break;
     }
 #undef PTMI_LAUNCH
+}
+
+void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
+                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
+                   StatCounters* stats, hipStream_t s) {
+    if (n_in <= 0) return;
+    BounceArgs a{sc, tm, st, fp, queue_in, n_in, queue_out, count_out, segments, stats};
+    const dim3 grid((n_in + kBlock - 1) / kBlock);
+    const size_t lds = bounce_lds_bytes(sc);
+    if (sc.traversal == TRAVERSAL_SWEEP) launch_bounce_mode<TRAVERSAL_SWEEP>(a, grid, lds, s);
+    else if (sc.traversal == TRAVERSAL_LANE) launch_bounce_mode<TRAVERSAL_LANE>(a, grid, lds, s);
+    else launch_bounce_mode<TRAVERSAL_STACK>(a, grid, lds, s);
 }
 
 void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* d_jump, uint64_t seed_base, hipStream_t s) {
@@ -457,17 +597,19 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
 // ---------------------------------------------------------------------------------------------
 // test hooks
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_QUADS>
+template <int MODE, bool HAS_QUADS>
 __global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_k(DeviceScene sc, int n, const float* o, const float* d, float t_min,
                                                                  float t_max, int* hit, int* prim, float* t_out, float* p_out, float* n_out) {
     extern __shared__ float4 smem[];
     int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const bool live = i < n;
+    const int j = live ? i : 0;
+    const f3 ro = mk3(o[3 * j], o[3 * j + 1], o[3 * j + 2]), rd = mk3(d[3 * j], d[3 * j + 1], d[3 * j + 2]);
     LaneCounters cn = {0, 0, 0, 0};
     float t = 0.0f; int k = -1;
-    const bool h = scene_intersect<HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, stack, ro, rd, t_min, t_max, t, k, cn);
+    const bool h = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, ro, rd, t_min, t_max, t, k, cn);
+    if (!live) return;
     hit[i] = h ? 1 : 0;
     prim[i] = h ? __float_as_int(sc.mats[3 * k].w) : -1;
     t_out[i] = h ? t : 0.0f;
@@ -482,8 +624,16 @@ void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const 
     if (n <= 0) return;
     const size_t lds = (size_t)sc.stack_entries * kBlock * sizeof(int);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    if (sc.has_quads) hipLaunchKernelGGL(ptmi_debug_intersect_k<true>, grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm);
-    else hipLaunchKernelGGL(ptmi_debug_intersect_k<false>, grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm);
+#define PTMI_DBG(M_, Q_) hipLaunchKernelGGL((ptmi_debug_intersect_k<M_, Q_>), grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm)
+    switch (sc.traversal * 2 + (sc.has_quads ? 1 : 0)) {
+        case 0: PTMI_DBG(TRAVERSAL_SWEEP, false); break;
+        case 1: PTMI_DBG(TRAVERSAL_SWEEP, true); break;
+        case 2: PTMI_DBG(TRAVERSAL_LANE, false); break;
+        case 3: PTMI_DBG(TRAVERSAL_LANE, true); break;
+        case 4: PTMI_DBG(TRAVERSAL_STACK, false); break;
+        default: PTMI_DBG(TRAVERSAL_STACK, true); break;
+    }
+#undef PTMI_DBG
 }
 
 __global__ void ptmi_debug_rng_k(const uint32_t* __restrict__ jump, unsigned long long seed_base, int n_pixels,

@@ -139,9 +139,14 @@ void SceneState::upload() {
     const int stride = num_quads ? 4 : 3;
     auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
     std::vector<float4> nodes(2 * bvh_nodes.size()), prims((size_t)stride * n), mats((size_t)3 * n);
+    // pre-order skip pointers: skip[i] = i + size of the subtree rooted at i
+    std::vector<int> subtree(bvh_nodes.size(), 1);
+    for (size_t i = bvh_nodes.size(); i-- > 0;)
+        if (!bvh_nodes[i].isLeaf()) subtree[i] = 1 + subtree[bvh_nodes[i].left_child] + subtree[bvh_nodes[i].right_child];
     for (size_t i = 0; i < bvh_nodes.size(); i++) {
         const BVHNode& b = bvh_nodes[i];
-        nodes[2 * i] = make_float4(b.bbox.min.x, b.bbox.min.y, b.bbox.min.z, bits(b.left_child));
+        if (!b.isLeaf() && b.left_child != (int)i + 1) throw ArgError("internal: BVH is not in pre-order");
+        nodes[2 * i] = make_float4(b.bbox.min.x, b.bbox.min.y, b.bbox.min.z, bits(b.isLeaf() ? b.left_child : (int)i + subtree[i]));
         nodes[2 * i + 1] = make_float4(b.bbox.max.x, b.bbox.max.y, b.bbox.max.z, bits(b.isLeaf() ? -b.prim_count : b.right_child));
     }
     for (int k = 0; k < n; k++) {                     // k = leaf-order slot
@@ -173,6 +178,16 @@ void SceneState::upload() {
     // LDS residency: the whole scene is staged per workgroup while it leaves room for >= 2 workgroups per CU
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
+    chooseTraversal();
+}
+
+// traversal choice (results are identical in all three; see device_scene.h)
+void SceneState::chooseTraversal() {
+    if (!d_nodes) return;
+    if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
+    else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
+    else d_scene.traversal = TRAVERSAL_LANE;
+    if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
 }
 
 // ------------------------------------------------------------------------------------------------

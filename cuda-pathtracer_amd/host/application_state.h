@@ -56,6 +56,8 @@ struct SceneState {
 
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_mats = nullptr;
     DeviceScene d_scene;
+    int sweep_max_prims = 64;                        // scenes up to this many primitives use the wave-uniform sweep
+    int force_traversal = -1;                        // test/benchmark override (TraversalMode), -1 = automatic
 
     // loadScene — application_state.h:367-464.  Throws IoError where the reference prints and returns.
     void loadScene(const std::string& filename, int subdivision_count, bool convert_quads);
@@ -63,6 +65,7 @@ struct SceneState {
     // host half only (parse + convert + subdivide + BVH), no device involved
     void loadSceneHost(const std::string& filename, int subdivision_count, bool convert_quads);
     void loadSceneArraysHost(std::vector<Primitive> prims);
+    void chooseTraversal();                          // picks d_scene.traversal from size/depth and the two knobs below
     void cleanup();                                  // application_state.h:466-490
     ~SceneState() { cleanup(); }
 

@@ -161,6 +161,11 @@ int  ptmi_host_camera_frame(const ptmi_camera*, int width, int height, float* ou
 int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows, int* rows_out);
 
 /* ---- unit-test hooks: single stages of the path on the device ------------- */
+/* Overrides how ptmi_bounce walks the BVH (results are identical in every mode): force_mode -1 = automatic,
+ * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack; sweep_max_prims = largest scene (primitives)
+ * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
+ * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
+int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int* out_mode);
 /* Scene::intersect (scene.h:39-110) for n rays given as-is (no normalisation). out_*: n each; p/nrm 3n. */
 int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm);

@@ -146,6 +146,62 @@ def test_frame_matches_oracle(R, name, sub, conv, W, H, spp, depth):
            (ost.samples, ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("name,sub,conv", [("cbox.obj", 0, False), ("cbox_quads.obj", 0, False), ("cbox.obj", 1, False)])
+def test_every_traversal_mode_gives_the_same_frame(R, mode, name, sub, conv):
+    """SWEEP (wave-uniform), LANE (stackless per lane) and STACK (explicit stack) must agree bit for bit."""
+    path = os.path.join(SCENES, name)
+    R.load_scene(path, sub, conv)
+    assert R.set_traversal(mode) == mode
+    try:
+        W, H, spp = 72, 40, 6
+        R.update_resolution(W, H)
+        R.set_config(spp=spp, max_depth=5, collect_stats=True)
+        st = R.render_frame()
+        rgb, rad = R.read_image()
+        orgb, orad, ost = OracleScene.load(path, sub, conv).render(default_camera(), W, H, spp, max_depth=5)
+        assert_same_image(rgb, rad, orgb, orad, f"{name} mode {mode}")
+        assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        O, D = _test_rays(OracleScene.load(path, sub, conv), np.random.default_rng(9), 600)
+        g = R.debug_intersect(O, D)
+        o = OracleScene.load(path, sub, conv)
+        for i in range(len(O)):
+            h = o.intersect(O[i], D[i])
+            assert g["hit"][i] == h.hit and g["prim"][i] == h.prim and (not h.hit or bits(g["t"][i]) == bits(F(h.t)))
+    finally:
+        R.set_traversal(-1)
+
+
+def test_deep_tree_uses_the_stack_walk_and_the_references_drop_rule(R):
+    """Centroids at 2^-i make the midpoint split peel one primitive per level: depth > 62, where the reference
+    silently drops children once its 64-entry stack holds 62 (scene.h:101-105).  Oracle and GPU must drop the same."""
+    n = 100
+    x = (2.0 ** 90 * 2.2 ** (-np.arange(n, dtype=np.float64))).astype(F)
+    verts = np.zeros((n, 4, 3), F)
+    for i in range(n):
+        z = F(i) * F(0.01)
+        verts[i, 0] = [x[i], -0.004, z]; verts[i, 1] = [x[i], 0.004, z]; verts[i, 2] = [x[i], 0.0, z + F(0.008)]
+    types = np.zeros(n, np.int32)
+    nr = np.tile(np.array([[1, 0, 0]], F), (n, 1)); b = np.full((n, 3), 0.5, F); le = np.ones((n, 3), F)
+    R.load_scene_arrays(types, verts, nr, b, le)
+    info = R.scene_info()
+    assert info["bvh_depth"] > 62
+    assert R.set_traversal(-1) == R.STACK and R.set_traversal(R.LANE) == R.STACK     # cannot be forced away
+    o = OracleScene.from_arrays(types, verts, nr, b, le)
+    rng = np.random.default_rng(2)
+    N = 800
+    O = np.stack([np.full(N, 2.0 ** 91), rng.uniform(-0.001, 0.001, N), rng.uniform(0, n * 0.01, N)], 1).astype(F)
+    D = np.tile(np.array([[-1, 0, 0]], F), (N, 1))
+    g = R.debug_intersect(O, D)
+    dropped = 0
+    for i in range(N):
+        h = o.intersect(O[i], D[i]); hl = o.intersect(O[i], D[i], use_bvh=False)
+        assert g["hit"][i] == h.hit and g["prim"][i] == h.prim
+        dropped += int(h.prim != hl.prim)
+    assert dropped > 0          # the drop rule really changes answers here, and both sides reproduce it
+    R.set_traversal(-1)
+
+
 def test_golden_fixtures(R):
     """Committed fixtures (tests/golden/*.npz, written by tests/golden/make_golden.py from the oracle)."""
     import glob
