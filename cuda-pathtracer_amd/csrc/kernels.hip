@@ -163,27 +163,66 @@ __device__ __forceinline__ bool quad_half(f3 v00, f3 edge1, f3 edge2, f3 o, f3 d
     return false;
 }
 
+// Branch-free accept test for the wave-uniform sweep.  Moller-Trumbore is evaluated exactly as triangle.h:64-96 /
+// quad.h:56-87 write it; the chain of early-outs becomes ONE sign test on a running minimum:
+//   |a| <  eps  reject   <=>  |a| - eps      < 0      (IEEE subtraction never flips a sign; denormals are on)
+//   u   <  0    reject   <=>  u              < 0
+//   u   >  1    reject   <=>  1 - u          < 0
+//   v   <  0    reject   <=>  v              < 0
+//   u+v >  1    reject   <=>  1 - (u + v)    < 0
+//   t > eps && t >= t_min  <=>  t - t_lo >= 0  with t_lo = max(t_min, nextafter(eps, +inf))
+// fminf ignores NaN operands exactly where the reference's `x < 0 || x > 1` forms let a NaN through; the final
+// `t < closest_t` (scene.h:90) rejects a NaN t.  Quad halves use the inclusive forms `|a| > eps`, `u >= 0 && ...`,
+// which differ from the above only for |a| == eps (handled through eps_lo = nextafter(eps)) and for NaN u/v; NaNs
+// need overflowing intermediates, which the host rules out (scene extent check) before choosing this code path.
+// min/max/cmp/cndmask are half-rate on gfx950, add/sub/mul full-rate: 3 min + 5 sub replace 7 cmp + 7 cndmask.
+__device__ __forceinline__ float accept_or_inf(float t, float abs_a_minus_eps, float u, float v, float t_lo) {
+    float m = fminf(fminf(abs_a_minus_eps, u), 1.0f - u);
+    m = fminf(fminf(m, v), 1.0f - (u + v));
+    m = fminf(m, t - t_lo);
+    return (m >= 0.0f) ? t : __builtin_inff();
+}
+__device__ __forceinline__ float mt_candidate(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float eps_for_a, float t_lo) {
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = rcp_rn(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(edge2, q);
+    return accept_or_inf(t, fabsf(a) - eps_for_a, u, v, t_lo);
+}
+// t_lo for a given t_min:  t > 1e-8f && t >= t_min  <=>  t >= t_lo
+__device__ __forceinline__ float mt_t_lo(float t_min) {
+    const float eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+    return t_min > 1e-8f ? t_min : eps_up;
+}
+
 __device__ __forceinline__ f3 xyz(const float4& v) { return mk3(v.x, v.y, v.z); }
 
 struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits; };
 
 // Slab test of scene.h:66-81 against [t_min, closest_t]; returns false when the reference would `continue`.
+// `t0 > tmin_box ? t0 : tmin_box` is written fmaxf(t0, tmin_box): identical for every input because tmin_box /
+// tmax_box are never NaN (a NaN t0/t1 - 0 * inf - is ignored by both forms) and the sign of a zero cannot reach the
+// final comparison.  One v_max/v_min instead of v_cmp + v_cndmask (all of them half-rate VALU ops on gfx950).
 __device__ __forceinline__ bool box_hit(const float4& n0, const float4& n1, f3 o, f3 inv, float t_min, float closest_t) {
     float tmin_box = t_min, tmax_box = closest_t;
     {
         float t0 = (n0.x - o.x) * inv.x, t1 = (n1.x - o.x) * inv.x;
         if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
     }
     {
         float t0 = (n0.y - o.y) * inv.y, t1 = (n1.y - o.y) * inv.y;
         if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
     }
     {
         float t0 = (n0.z - o.z) * inv.z, t1 = (n1.z - o.z) * inv.z;
         if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = t0 > tmin_box ? t0 : tmin_box; tmax_box = t1 < tmax_box ? t1 : tmax_box;
+        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
     }
     return !(tmax_box < tmin_box);
 }
@@ -282,51 +321,42 @@ __device__ __forceinline__ bool intersect_lane(const float4* __restrict__ nodes,
 // no stack, no per-lane LDS read, and lanes at different depths of the tree never serialise against each other.
 // The wave pays for the UNION of its lanes' visits, so this is used only for scenes of a few dozen primitives.
 // Must be called from wave-uniform control flow (dead lanes pass live = false).
-// Scene arrays viewed through the CONSTANT address space: with a wave-uniform index the compiler then emits
-// s_load_dwordx4 (scalar cache, SGPR destination) instead of a per-lane global_load.  Legal because no kernel
-// ever writes the scene.
-typedef const __attribute__((address_space(4))) float* const_f_ptr;
-struct const_f4_ptr {                                   // float4 array seen as scalars (keeps the host pass happy)
-    const_f_ptr p;
-    __device__ __forceinline__ float4 operator[](int i) const { return make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }
-};
-__device__ __forceinline__ const_f4_ptr as_constant(const float4* p) {
-    const_f4_ptr r;
-    r.p = (const_f_ptr)(const __attribute__((address_space(1))) float*)reinterpret_cast<const float*>(p);
-    return r;
-}
-
 template <bool HAS_QUADS>
-__device__ __forceinline__ void leaf_prim_uniform(const_f4_ptr prims, int prim_stride, int k, f3 o, f3 d, float t_min,
-                                                  float& closest_t, int& slot_hit, bool& hit_anything) {
+__device__ __forceinline__ void leaf_prim_uniform(const float4* prims, int prim_stride, int k, f3 o, f3 d, float t_lo,
+                                                  float& closest_t, int& slot_hit) {
+    // k is wave-uniform: these are broadcast LDS reads, the operands land in VGPRs (an SGPR operand would halve
+    // the issue rate of every multiply/subtract that uses it)
     const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+    const float eps = 1e-8f, eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
     float t;
-    bool h;
-    if (HAS_QUADS && __float_as_int(p0.w) != 0) {                              // wave-uniform branch
+    if (HAS_QUADS && __builtin_amdgcn_readfirstlane(__float_as_int(p0.w)) != 0) {   // wave-uniform branch
         const float4 p3 = prims[k * prim_stride + 3];
-        float c = closest_t;
-        h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);
-        h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;
-        t = c;
+        // Quad::intersect: closest = t_max (= closest_t); each half accepts t < closest, second half sees the first's result
+        const float t1 = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps_up, t_lo);     // (v00, v10, v11), |a| > eps
+        const float c1 = fminf(t1, closest_t);
+        const float t2 = mt_candidate(xyz(p0), xyz(p2), xyz(p3), o, d, eps_up, t_lo);     // (v00, v11, v01)
+        t = fminf(t2, c1);                        // == closest_t when neither half was accepted
     } else {
-        h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
+        t = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo);                     // !(|a| < eps)
     }
-    if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }
+    const bool closer = t < closest_t;            // tri: t <= t_max && t < closest_t ; quad: hit && temp.t < closest_t (scene.h:89-90)
+    closest_t = fminf(t, closest_t);
+    slot_hit = closer ? k : slot_hit;
 }
 
 template <bool HAS_QUADS, bool STATS>
-__device__ __forceinline__ bool intersect_sweep(const float4* __restrict__ nodes_g, const float4* __restrict__ prims_g, int prim_stride,
+__device__ __forceinline__ bool intersect_sweep(const float4* nodes, const float4* prims, int prim_stride,
                                                 int n_nodes, bool live, f3 o, f3 d, float t_min, float t_max,
                                                 float& t_hit, int& slot_hit, LaneCounters& cn) {
-    const const_f4_ptr nodes = as_constant(nodes_g), prims = as_constant(prims_g);
-    bool hit_anything = false;
     float closest_t = t_max;
+    slot_hit = -1;
     const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    const float t_lo = mt_t_lo(t_min);
     int cur = live ? 0 : n_nodes;
     for (int n = 0; n < n_nodes; n++) {
         if (cur == n) {
             // readfirstlane pins the index to an SGPR: inside this branch the optimiser knows cur == n and would
-            // otherwise address the node through the per-lane cursor (vector loads)
+            // otherwise address the node through the per-lane cursor
             const int nu = __builtin_amdgcn_readfirstlane(n);
             const float4 n0 = nodes[2 * nu], n1 = nodes[2 * nu + 1];
             if (STATS) cn.node_visits++;
@@ -338,14 +368,14 @@ __device__ __forceinline__ bool intersect_sweep(const float4* __restrict__ nodes
                 if (pass) {
                     for (int i = 0; i < -b; i++) {
                         if (STATS) cn.prim_tests++;
-                        leaf_prim_uniform<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
+                        leaf_prim_uniform<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_lo, closest_t, slot_hit);
                     }
                 }
             } else if (!pass) cur = a;
         }
     }
     t_hit = closest_t;
-    return hit_anything;
+    return slot_hit >= 0;
 }
 
 template <int MODE, bool HAS_QUADS, bool STATS>
@@ -390,11 +420,12 @@ struct BounceArgs {
     StatCounters* stats;
 };
 
-// LDS: [nodes | prims] when LDS_GEOM, [mats] when LDS_GEOM or MODE == SWEEP, then the traversal stacks (STACK only).
+// LDS: [nodes | prims | mats] when LDS_GEOM (always for SWEEP), then the traversal stacks (STACK only).
 template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
 __global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
-    constexpr bool LDS_MATS = LDS_GEOM || MODE == TRAVERSAL_SWEEP;
+    static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
+    constexpr bool LDS_MATS = LDS_GEOM;
     const int n_node_vec = 2 * a.sc.n_nodes, n_prim_vec = a.sc.prim_stride * a.sc.n_prims, n_mat_vec = 3 * a.sc.n_prims;
     const float4* __restrict__ nodes = a.sc.nodes; const float4* __restrict__ prims = a.sc.prims; const float4* mats = a.sc.mats;
     float4* lds = smem;
@@ -514,30 +545,30 @@ __global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
     size_t b = 0;
-    const bool geom = sc.lds_resident && sc.traversal != TRAVERSAL_SWEEP;
-    if (geom) b += (size_t)(2 * sc.n_nodes + sc.prim_stride * sc.n_prims) * sizeof(float4);
-    if (geom || sc.traversal == TRAVERSAL_SWEEP) b += (size_t)3 * sc.n_prims * sizeof(float4);
+    const bool geom = sc.lds_resident || sc.traversal == TRAVERSAL_SWEEP;
+    if (geom) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);
     if (sc.traversal == TRAVERSAL_STACK) b += (size_t)sc.stack_entries * kBlock * sizeof(int);
     return b;
 }
 
+template <int MODE, bool G_, bool Q_, bool S_>
+static void launch_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_>), grid, dim3(kBlock), lds, s, a);
+}
+template <int MODE, bool G_>
+static void launch_qs(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
+    switch (key) {
+        case 0: launch_one<MODE, G_, false, false>(a, grid, lds, s); break;
+        case 1: launch_one<MODE, G_, false, true>(a, grid, lds, s); break;
+        case 2: launch_one<MODE, G_, true, false>(a, grid, lds, s); break;
+        default: launch_one<MODE, G_, true, true>(a, grid, lds, s); break;
+    }
+}
 template <int MODE>
 static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    const bool geom = a.sc.lds_resident && MODE != TRAVERSAL_SWEEP;
-    const int key = (geom ? 4 : 0) | (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    const dim3 block(kBlock);
-#define PTMI_LAUNCH(G_, Q_, S_) hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_>), grid, block, lds, s, a)
-    switch (key) {
-        case 0: PTMI_LAUNCH(false, false, false); break;
-        case 1: PTMI_LAUNCH(false, false, true); break;
-        case 2: PTMI_LAUNCH(false, true, false); break;
-        case 3: PTMI_LAUNCH(false, true, true); break;
-        case 4: PTMI_LAUNCH(true, false, false); break;
-        case 5: PTMI_LAUNCH(true, false, true); break;
-        case 6: PTMI_LAUNCH(true, true, false); break;
-        default: PTMI_LAUNCH(true, true, true); break;
-    }
-#undef PTMI_LAUNCH
+    if (MODE == TRAVERSAL_SWEEP || a.sc.lds_resident) launch_qs<MODE, true>(a, grid, lds, s);
+    else if (MODE != TRAVERSAL_SWEEP) launch_qs<MODE == TRAVERSAL_SWEEP ? TRAVERSAL_LANE : MODE, false>(a, grid, lds, s);
 }
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,

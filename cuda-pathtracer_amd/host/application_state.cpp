@@ -188,6 +188,7 @@ void SceneState::chooseTraversal() {
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
     else d_scene.traversal = TRAVERSAL_LANE;
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
+    if (d_scene.traversal == TRAVERSAL_SWEEP && !d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;   // the sweep reads through LDS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libptmi.so")
+LIB_PATH = os.environ.get("PTMI_LIB") or os.path.join(os.path.dirname(_HERE), "libptmi.so")   # PTMI_LIB: A/B experiments only
 
 EXPORTS = [
     "ptmi_ctx_create", "ptmi_ctx_destroy", "ptmi_last_error", "ptmi_default_camera", "ptmi_default_config",
