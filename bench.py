@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import ptmi  # noqa: E402
+import ptmi_dist  # noqa: E402
 
 SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
 SPP, MAX_DEPTH, BASE_SIDE, ROW_BLOCK = 256, 8, 1024, 8
@@ -122,30 +123,17 @@ def main():
     allocate()
     rows = r.local_rows()
     n_local_rows = len(rows)
-    max_rows = int(max(len(ptmi.host_local_row_map(side, world, k, ROW_BLOCK)) for k in range(world)))
 
     # gather plumbing (torch = device memory + RCCL only)
     dev = torch.device("cuda", local_rank)
-    send_rad = torch.zeros((max_rows, side, 3), dtype=torch.float32, device=dev)
-    send_rgb = torch.zeros((max_rows, side, 3), dtype=torch.uint8, device=dev)
-    if world > 1 and rank == 0:
-        recv_rad = [torch.empty_like(send_rad) for _ in range(world)]
-        recv_rgb = [torch.empty_like(send_rgb) for _ in range(world)]
-        row_maps = [torch.from_numpy(ptmi.host_local_row_map(side, world, k, ROW_BLOCK).astype(np.int64)).to(dev) for k in range(world)]
-        frame_rad = torch.empty((side, side, 3), dtype=torch.float32, device=dev)
-        frame_rgb = torch.empty((side, side, 3), dtype=torch.uint8, device=dev)
+    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, dev)
+    assert fg.n_local == n_local_rows
 
     def step(stats):
         st = r.render_frame(want_stats=stats)
         if world > 1:
-            r.copy_image_device(send_rgb.data_ptr(), send_rad.data_ptr())
-            dist.gather(send_rad, recv_rad if rank == 0 else None, dst=0)
-            dist.gather(send_rgb, recv_rgb if rank == 0 else None, dst=0)
-            if rank == 0:
-                for k in range(world):
-                    m = row_maps[k]
-                    frame_rad[m] = recv_rad[k][: len(m)]
-                    frame_rgb[m] = recv_rgb[k][: len(m)]
+            r.copy_image_device(fg.send_rgb.data_ptr(), fg.send_rad.data_ptr())
+            fg.gather()                              # the single RCCL exchange of a frame
         return st
 
     def barrier():

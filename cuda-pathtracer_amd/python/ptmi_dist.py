@@ -1,0 +1,52 @@
+"""Multi-GPU frame assembly: interleaved row-block tiles -> one frame on the destination rank.
+
+The render path shards by independent pixels (RNG streams are keyed by the global pixel index), so the only
+exchange step of a frame is this gather at its end: every rank contributes its rows, the destination places
+them.  torch.distributed is used as plumbing only (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the
+CPU tests); tile payloads are uniform-size (padded to the largest rank) so ONE gather call moves each image.
+"""
+import numpy as np
+import torch
+
+import ptmi
+
+
+def row_maps(height, world, row_block):
+    """Global row indices owned by each rank (same arithmetic as the C ABI's ptmi_host_local_row_map)."""
+    return [ptmi.host_local_row_map(height, world, k, row_block).astype(np.int64) for k in range(world)]
+
+
+class FrameGather:
+    def __init__(self, dist, width, height, world, rank, row_block, device, dst=0):
+        self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
+        self.width, self.height = width, height
+        self.maps = row_maps(height, world, row_block)
+        self.max_rows = max(len(m) for m in self.maps)
+        self.n_local = len(self.maps[rank])
+        # one payload per rank: [float32 radiance | uint8 rgb] so a frame needs exactly ONE collective
+        n_px = self.max_rows * width
+        self._n_rad_bytes = n_px * 12
+        self.send = torch.zeros(n_px * 15, dtype=torch.uint8, device=device)
+        self.send_rad = self.send[: self._n_rad_bytes].view(torch.float32).view(self.max_rows, width, 3)
+        self.send_rgb = self.send[self._n_rad_bytes:].view(self.max_rows, width, 3)
+        if rank == dst:
+            self.recv = [torch.empty_like(self.send) for _ in range(world)]
+            self.maps_t = [torch.from_numpy(m).to(device) for m in self.maps]
+            self.frame_rad = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+            self.frame_rgb = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
+
+    def gather(self):
+        """send_rad / send_rgb[:n_local] must hold this rank's rows.  Returns (frame_rad, frame_rgb) on dst, else None."""
+        if self.world == 1:
+            return self.send_rad[: self.n_local], self.send_rgb[: self.n_local]
+        is_dst = self.rank == self.dst
+        self.dist.gather(self.send, self.recv if is_dst else None, dst=self.dst)
+        if not is_dst:
+            return None
+        for k in range(self.world):
+            m = self.maps_t[k]
+            rad = self.recv[k][: self._n_rad_bytes].view(torch.float32).view(self.max_rows, self.width, 3)
+            rgb = self.recv[k][self._n_rad_bytes:].view(self.max_rows, self.width, 3)
+            self.frame_rad[m] = rad[: len(m)]
+            self.frame_rgb[m] = rgb[: len(m)]
+        return self.frame_rad, self.frame_rgb

@@ -1,0 +1,25 @@
+"""N > 1 path on CPU: world_size-2 and -3 gloo processes shard a frame by interleaved row blocks, gather it with
+the product's FrameGather and must reproduce the unsharded frame bit-for-bit (rendering by the oracle)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("world,W,H,row_block", [(2, 40, 37, 8), (2, 32, 16, 4), (3, 24, 50, 8)])
+def test_gloo_tile_gather_reassembles_the_frame(world, W, H, row_block):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "dist_worker.py"), str(W), str(H), "3", str(row_block)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "dist-gather OK" in p.stdout

@@ -1,0 +1,142 @@
+"""BASELINE.json configurations at FULL size on one MI355X.
+
+Where the oracle can afford it the whole frame is compared bit-for-bit (config 2: 268 M samples, ~20 s of CPU);
+for the larger frames the oracle renders a band of rows at full spp (pixels are independent, so rows of the
+full-size frame are exactly reproducible in isolation) and the rest is covered by size-independent properties:
+tile-union == unsharded frame (the multi-GPU contract), independence from segments_per_launch (scheduling), and
+independence from the traversal mode.  Tolerance everywhere: exact (0 differing pixels, RMSE 0).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ptmi
+import ptmi_scenes
+from oracle_binding import OracleScene, SCENES, default_camera
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, F).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def R():
+    r = ptmi.Renderer(0)
+    yield r
+    r.close()
+
+
+def check_rows_against_oracle(o, rad, rgb, W, H, spp, depth, y0, y1):
+    orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=depth, y0=y0, y1=y1)
+    nd = int((bits(rad[y0:y1]) != bits(orad[y0:y1])).any(axis=-1).sum())
+    rmse = float(np.sqrt(np.mean((rad[y0:y1].astype(np.float64) - orad[y0:y1]) ** 2)))
+    assert nd == 0 and rmse == 0.0, f"rows {y0}:{y1}: {nd} pixels differ, RMSE {rmse:.3e}"
+    assert (rgb[y0:y1] == orgb[y0:y1]).all()
+    return ost
+
+
+def test_config2_cbox_1024_256spp_depth8_whole_frame(R):
+    W = H = 1024; spp, depth = 256, 8
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path); R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=True)
+    st = R.render_frame()
+    rgb, rad = R.read_image()
+    o = OracleScene.load(path)
+    ost = check_rows_against_oracle(o, rad, rgb, W, H, spp, depth, 0, H)
+    assert (st.samples, st.rays, st.node_visits, st.prim_tests, st.hits) == \
+           (ost.samples, ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+    assert st.samples == W * H * spp
+    # properties on the same full-size frame: scheduling knob, traversal mode, 8-way tiling
+    R.set_config(collect_stats=False)
+    for seg, mode in ((1, -1), (100000, -1), (8, ptmi.Renderer.LANE)):
+        R.set_traversal(mode); R.update_resolution(W, H); R.set_config(segments_per_launch=seg)
+        R.render_frame()
+        rgb2, rad2 = R.read_image()
+        assert (bits(rad2) == bits(rad)).all() and (rgb2 == rgb).all(), (seg, mode)
+    R.set_traversal(-1); R.set_config(segments_per_launch=0)
+    union = np.full_like(rad, -1)
+    for rank in range(8):
+        R.update_resolution(W, H, n_ranks=8, rank=rank, row_block=8)
+        R.render_frame()
+        union[R.local_rows()] = R.read_image()[1]
+    assert (bits(union) == bits(rad)).all()
+
+
+def test_config3_cbox_quads_1920x1080_1024spp(R):
+    W, H, spp, depth = 1920, 1080, 1024, 5          # native quads, Russian roulette from depth 3 (always on)
+    path = os.path.join(SCENES, "cbox_quads.obj")
+    R.load_scene(path, 0, False); R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=False)
+    st = R.render_frame()
+    rgb, rad = R.read_image()
+    assert st.samples == W * H * spp
+    o = OracleScene.load(path)
+    check_rows_against_oracle(o, rad, rgb, W, H, spp, depth, 536, 544)
+    check_rows_against_oracle(o, rad, rgb, W, H, spp, depth, 1079, 1080)
+    R.update_resolution(W, H); R.set_config(segments_per_launch=100000)
+    R.render_frame()
+    assert (bits(R.read_image()[1]) == bits(rad)).all()
+    R.set_config(segments_per_launch=0)
+    # image sanity: energy present, borders black (25 % of primary rays miss)
+    assert 0.05 < float(rad.mean()) < 0.5 and float(rad[:, :40].max()) == 0.0
+
+
+def test_config4_cbox_4096_512spp_tiled_8_ways(R):
+    W = H = 4096; spp, depth = 512, 5
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path)
+    R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=False)
+    o = OracleScene.load(path)
+    # the unsharded frame (8.6 G samples) ...
+    R.update_resolution(W, H)
+    st = R.render_frame()
+    assert st.samples == W * H * spp
+    _, full = R.read_image(rgb8=False)
+    check_rows_against_oracle(o, full, R.read_image()[0], W, H, spp, depth, 2048, 2050)
+    # ... equals the union of the 8 ranks' interleaved 8-row blocks
+    checksum = 0
+    for rank in range(8):
+        R.update_resolution(W, H, n_ranks=8, rank=rank, row_block=8)
+        assert len(R.local_rows()) == H // 8
+        R.render_frame()
+        _, tile = R.read_image(rgb8=False)
+        assert (bits(tile) == bits(full[R.local_rows()])).all(), rank
+        checksum += int(bits(tile).astype(np.uint64).sum())
+    assert checksum == int(bits(full).astype(np.uint64).sum())
+
+
+def test_config5_one_million_triangles_2048_2048spp(R):
+    W = H = 2048; spp, depth = 2048, 8
+    base = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj")).prims()
+    sc = ptmi_scenes.tessellated_cornell(base, 256, 128, seed=1)
+    assert len(sc["type"]) == 1048576
+    args = (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
+    R.load_scene_arrays(*args)
+    assert R.scene_info()["n_prims"] == 1048576 and R.set_traversal(-1) == R.LANE
+    o = OracleScene.from_arrays(*args)
+    # rank 3 of 8 at FULL spp (one GPU's share of the 8-GPU configuration): 1/8 of 8.6 G samples
+    R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=False)
+    R.update_resolution(W, H, n_ranks=8, rank=3, row_block=8)
+    st = R.render_frame()
+    rows = R.local_rows()
+    assert st.samples == len(rows) * W * spp
+    rgb, rad = R.read_image()
+    y = int(rows[100])                                   # one full-spp row of the tile against the oracle
+    orgb, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, y0=y, y1=y + 1)
+    assert (bits(rad[100]) == bits(orad[y])).all() and (rgb[100] == orgb[y]).all()
+    # whole 2048^2 frame at reduced spp: tile union == unsharded, and scheduling independence
+    R.set_config(spp=16)
+    R.update_resolution(W, H); R.render_frame()
+    _, full = R.read_image(rgb8=False)
+    check_rows_against_oracle(o, full, R.read_image()[0], W, H, 16, depth, 1000, 1004)
+    for rank in (0, 5):
+        R.update_resolution(W, H, n_ranks=8, rank=rank, row_block=8); R.render_frame()
+        assert (bits(R.read_image(rgb8=False)[1]) == bits(full[R.local_rows()])).all()
+    R.update_resolution(W, H); R.set_config(segments_per_launch=3); R.render_frame()
+    assert (bits(R.read_image(rgb8=False)[1]) == bits(full)).all()
+    R.set_config(segments_per_launch=0)
