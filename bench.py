@@ -154,12 +154,13 @@ def main():
 
     kernel_ms = 0.0
     launches = 0
+    visits = 0
     frame_dev_s = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = step(True)
-        kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; frame_dev_s += st.seconds
+        kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; visits += st.path_visits; frame_dev_s += st.seconds
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -172,14 +173,18 @@ def main():
     # roofline of the dominant kernel on THIS rank: algorithmic bytes of its launches / their summed duration
     local_samples = float(n_local_rows) * side * spp * args.steps
     achieved = local_samples * bytes_per_sample / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes; see profiles/README.md)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_bounce.json")
-    if os.path.exists(pmc):
+    if world == 1 and os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-
+    # what this design can send to HBM at all: every queued pixel reads and writes its 88-byte state once per
+    # launch (+ 4-byte queue entries); nodes/triangles/materials are LDS-resident for this scene
+    state_bytes = visits * (88 + 88 + 4 + 4)
     if rank == 0:
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -195,7 +200,12 @@ def main():
                          "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                          "algorithmic_bytes_per_launch": round(local_samples * bytes_per_sample / max(launches, 1), 1),
-                         "kernel_share_of_frame": round(kernel_ms * 1e-3 / max(frame_dev_s, 1e-12), 4)},
+                         "kernel_share_of_frame": round(kernel_ms * 1e-3 / max(frame_dev_s, 1e-12), 4),
+                         "path_state_bytes_per_launch": round(state_bytes / max(launches, 1), 1),
+                         "path_state_GBps": round(state_bytes / max(kernel_ms * 1e-3, 1e-12) / 1e9, 1),
+                         "note": "algorithmic bytes follow SURVEY 8(d) and count node/triangle/material reads as memory "
+                                 "traffic; for this 32-triangle scene they are served from LDS, so the kernel is VALU-issue-bound "
+                                 "and only the path-state share (path_state_*) can reach HBM"},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(side)

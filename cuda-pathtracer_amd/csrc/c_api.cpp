@@ -277,7 +277,7 @@ int ptmi_render_frame(ptmi_ctx* c, ptmi_stats* stats) {
         FrameStats fs;
         renderFrame(c->app, stats ? &fs : nullptr);
         if (stats) {
-            stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches;
+            stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
             stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
             stats->prim_tests = fs.prim_tests; stats->hits = fs.hits;
         }
@@ -356,6 +356,23 @@ int ptmi_debug_rng(ptmi_ctx* c, uint64_t seed_base, int n_pixels, const int* pix
         PTMI_HIP(hipGetLastError());
         PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
         d_out.download(out, (size_t)n_pixels * count);
+    });
+}
+
+int ptmi_debug_rcp_check(ptmi_ctx* c, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first_bad_bits) {
+    return guarded([&] {
+        need(c && mismatches && first_bad_bits, "NULL argument");
+        need(count > 0 && count <= (1ull << 32), "count must be in [1, 2^32]");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        DevBuf<unsigned long long> d(2);
+        const unsigned long long init[2] = {0ull, ~0ull};
+        d.upload(init, 2);
+        launch_debug_rcp(first_bits, count, d.p, c->app.render.stream);
+        PTMI_HIP(hipGetLastError());
+        PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
+        unsigned long long h[2];
+        d.download(h, 2);
+        *mismatches = h[0]; *first_bad_bits = h[0] ? (uint32_t)h[1] : 0u;
     });
 }
 

@@ -94,6 +94,7 @@ size_t bounce_lds_bytes(const DeviceScene& sc);
 void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
                             int* hit, int* prim, float* t, float* p, float* nrm, hipStream_t s);
 void launch_debug_rng(const uint32_t* d_jump, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out, hipStream_t s);
+void launch_debug_rcp(unsigned int first_bits, unsigned long long count, unsigned long long* d_out, hipStream_t s);
 void launch_debug_cosine(int n, const float* normals, const float* u, const float* v, float* out, hipStream_t s);
 
 }  // namespace ptmi

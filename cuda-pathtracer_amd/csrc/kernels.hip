@@ -131,7 +131,7 @@ __device__ __forceinline__ bool tri_test(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, 
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);
     if (fabsf(a) < EPSILON) return false;
-    const float f = rcp_rn(a);
+    const float f = rcp_exact_normal(a);                  // == 1.0f / a for every normal a (see pt_vec.h)
     const f3 s = o - v0;
     const float u = f * dot(s, h);
     if (u < 0.0f || u > 1.0f) return false;
@@ -148,7 +148,7 @@ __device__ __forceinline__ bool quad_half(f3 v00, f3 edge1, f3 edge2, f3 o, f3 d
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);
     if (fabsf(a) > EPSILON) {
-        const float f = rcp_rn(a);
+        const float f = rcp_exact_normal(a);
         const f3 s = o - v00;
         const float u = f * dot(s, h);
         if (u >= 0.0f && u <= 1.0f) {
@@ -176,22 +176,22 @@ __device__ __forceinline__ bool quad_half(f3 v00, f3 edge1, f3 edge2, f3 o, f3 d
 // which differ from the above only for |a| == eps (handled through eps_lo = nextafter(eps)) and for NaN u/v; NaNs
 // need overflowing intermediates, which the host rules out (scene extent check) before choosing this code path.
 // min/max/cmp/cndmask are half-rate on gfx950, add/sub/mul full-rate: 3 min + 5 sub replace 7 cmp + 7 cndmask.
-__device__ __forceinline__ float accept_or_inf(float t, float abs_a_minus_eps, float u, float v, float t_lo) {
-    float m = fminf(fminf(abs_a_minus_eps, u), 1.0f - u);
-    m = fminf(fminf(m, v), 1.0f - (u + v));
-    m = fminf(m, t - t_lo);
-    return (m >= 0.0f) ? t : __builtin_inff();
-}
 __device__ __forceinline__ float mt_candidate(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float eps_for_a, float t_lo) {
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);
-    const float f = rcp_rn(a);
+    const float f = rcp_exact_normal(a);                  // garbage for |a| < 2^-126, which the eps test rejects anyway
     const f3 s = o - v0;
     const float u = f * dot(s, h);
+    // wave-level early-out: if the (a, u) tests already reject every lane that is testing this primitive, the second
+    // half of Moller-Trumbore is skipped for the whole wave (coherent camera-ray waves do this for most primitives)
+    const float m1 = fminf(fminf(fabsf(a) - eps_for_a, u), 1.0f - u);
+    if (!__any(m1 >= 0.0f)) return __builtin_inff();
     const f3 q = cross(s, edge1);
     const float v = f * dot(d, q);
     const float t = f * dot(edge2, q);
-    return accept_or_inf(t, fabsf(a) - eps_for_a, u, v, t_lo);
+    float m = fminf(fminf(m1, v), 1.0f - (u + v));
+    m = fminf(m, t - t_lo);
+    return (m >= 0.0f) ? t : __builtin_inff();
 }
 // t_lo for a given t_min:  t > 1e-8f && t >= t_min  <=>  t >= t_lo
 __device__ __forceinline__ float mt_t_lo(float t_min) {
@@ -692,6 +692,22 @@ void launch_debug_rng(const uint32_t* d_jump, uint64_t seed_base, int n_pixels, 
     if (n_pixels <= 0) return;
     hipLaunchKernelGGL(ptmi_debug_rng_k, dim3((n_pixels + 63) / 64), dim3(64), 0, s, d_jump, (unsigned long long)seed_base,
                        n_pixels, pixels, count, out);
+}
+
+// exhaustive check of rcp_exact_normal against the IEEE quotient over a range of bit patterns
+__global__ void ptmi_debug_rcp_k(unsigned int first, unsigned long long count, unsigned long long* out /* [0]=mismatches [1]=first bad bits+1 */) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, first_bad = ~0ull;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count; i += stride) {
+        const unsigned int bits = first + (unsigned int)i;
+        const float a = __uint_as_float(bits);
+        const float want = 1.0f / a, got = rcp_exact_normal(a);
+        if (__float_as_uint(want) != __float_as_uint(got) && !(want != want && got != got)) { bad++; if (first_bad == ~0ull) first_bad = bits; }
+    }
+    if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first_bad); }
+}
+void launch_debug_rcp(unsigned int first, unsigned long long count, unsigned long long* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(ptmi_debug_rcp_k, dim3(4096), dim3(256), 0, s, first, count, d_out);
 }
 
 __global__ void ptmi_debug_cosine_k(int n, const float* normals, const float* u, const float* v, float* out) {

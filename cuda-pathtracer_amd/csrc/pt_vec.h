@@ -28,6 +28,22 @@ PT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }                      
 // explicitly): `/` and __builtin_sqrtf then lower to the IEEE-exact v_div_scale/fmas/fixup and scaled-sqrt
 // sequences.  NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS that is the 1-ulp v_sqrt_f32.
 PT_HD float rcp_rn(float t) { return 1.0f / t; }
+
+// Correctly rounded 1/a for the Moller-Trumbore determinant, in 1 v_rcp_f32 + 4 v_fma_f32 instead of the compiler's
+// 10-instruction IEEE division (v_div_scale x2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup; the scale/fmas/fixup
+// ops are half-rate).  Two Newton steps on the <= 1 ulp hardware seed; without the scaling steps this is exact only
+// while neither a nor 1/a leaves the normal range.  tests/test_gpu_parity.py::test_fast_reciprocal_is_exact checks
+// ALL 2^32 bit patterns against the IEEE quotient on the device and pins the interval [2^-100, 2^100] used here;
+// outside it the caller's result is either rejected anyway (|a| < 1e-8) or unreachable for scenes that pass the
+// host's extent check.  Device only: the CPU oracle keeps the true division.
+__device__ __forceinline__ float rcp_exact_normal(float a) {
+    float r = __builtin_amdgcn_rcpf(a);
+    float e = __builtin_fmaf(-a, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-a, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return r;
+}
 PT_HD float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 PT_HD f3 div_scalar(f3 v, float t) { float k = rcp_rn(t); return mk3(v.x * k, v.y * k, v.z * k); }
 PT_HD float dot(f3 a, f3 b) { float s = a.x * b.x; s += a.y * b.y; s += a.z * b.z; return s; }   // vector.h:198-203 (0 + x is exact)

@@ -135,6 +135,15 @@ void SceneState::buildBVH() {
 
 void SceneState::upload() {
     const int n = (int)h_primitives.size();
+    // The kernels' short reciprocal (pt_vec.h: rcp_exact_normal) equals the IEEE quotient while the Moller-Trumbore
+    // determinant stays below 2^126; |a| <= 2 |e1| |e2| (|d| = 1), so edge components below 2^60 are always safe.
+    for (const Primitive& p : h_primitives)
+        for (int k = 0; k < (p.type == PRIM_QUAD ? 4 : 3); k++) {
+            const f3 e = p.v[k] - p.v[0];
+            const float m = fmaxf(fabsf(e.x), fmaxf(fabsf(e.y), fabsf(e.z)));
+            const float c = fabsf(p.v[k].x) + fabsf(p.v[k].y) + fabsf(p.v[k].z);
+            if (!(m < 1.0e18f) || !(c < 3.0e38f)) throw ArgError("scene coordinates must be finite and primitive edges shorter than 1e18");
+        }
     // ---- SoA re-layout (device_scene.h) ----
     const int stride = num_quads ? 4 : 3;
     auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
@@ -295,7 +304,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
 
     const int n_local = (int)r.n_local;
-    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 8;
+    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
     hipStream_t s = r.stream;
     const bool want_stats = g.config.collect_stats;
 
@@ -314,9 +323,10 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     int n_active = n_local;
     const int* q_in = nullptr;                         // identity queue for the first launch
     int cur = 0;
-    uint64_t launches = 0;
+    uint64_t launches = 0, visits = 0;
     const size_t first_kernel_event = n_ev;
     while (n_active > 0) {
+        visits += (uint64_t)n_active;
         PTMI_HIP(hipMemsetAsync(r.d_count, 0, sizeof(int), s));
         const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
         if (stats) PTMI_HIP(hipEventRecord(e0, s));
@@ -349,6 +359,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         }
         stats->bounce_kernel_ms = kms;
         stats->bounce_launches = launches;
+        stats->path_visits = visits;
         stats->samples = (uint64_t)n_local * (uint64_t)g.config.spp;
         if (want_stats) {
             StatCounters c;

@@ -97,7 +97,7 @@ struct RenderState {
 
 struct FrameStats {
     double seconds = 0, bounce_kernel_ms = 0;
-    uint64_t bounce_launches = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0;
+    uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0;
 };
 
 struct ApplicationState {

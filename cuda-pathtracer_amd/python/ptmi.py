@@ -21,7 +21,7 @@ EXPORTS = [
     "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
     "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
     "ptmi_copy_image_device",
-    "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal",
+    "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
 ]
@@ -42,7 +42,7 @@ class Tiling(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("seconds", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64),
+    _fields_ = [("seconds", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("path_visits", C.c_uint64),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64)]
 
@@ -90,6 +90,7 @@ def lib():
         L.ptmi_debug_rng.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_int, vp]
         L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.ptmi_debug_set_traversal.argtypes = [vp, C.c_int, C.c_int, ip]
+        L.ptmi_debug_rcp_check.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.ptmi_host_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.ptmi_host_scene_from_arrays.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.POINTER(vp)]
         L.ptmi_host_scene_free.argtypes = [vp]; L.ptmi_host_scene_free.restype = None
@@ -294,6 +295,11 @@ class Renderer:
         m = C.c_int(-1)
         self._ck(self.L.ptmi_debug_set_traversal(self.h, int(force_mode), int(sweep_max_prims), C.byref(m)))
         return m.value
+
+    def debug_rcp_check(self, first_bits, count):
+        bad = C.c_uint64(); first = C.c_uint32()
+        self._ck(self.L.ptmi_debug_rcp_check(self.h, int(first_bits), int(count), C.byref(bad), C.byref(first)))
+        return bad.value, first.value
 
     def debug_intersect(self, o, d, t_min=1e-4, t_max=3.4028234663852886e38):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)

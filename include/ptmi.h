@@ -85,6 +85,7 @@ typedef struct {
     double   seconds;          /* device time of the frame (HIP events around all launches) */
     double   bounce_kernel_ms; /* summed duration of the dominant kernel (ptmi_bounce) */
     uint64_t bounce_launches;
+    uint64_t path_visits;      /* sum over launches of queued pixels: each reads + writes its 88-byte state once */
     uint64_t samples;          /* local pixels * spp */
     uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */
 } ptmi_stats;
@@ -171,6 +172,9 @@ int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float
                          int* hit, int* prim, float* t, float* p, float* nrm);
 /* render_init + curand_uniform: first `count` uniforms of pixel stream (seed_base+pixel, subsequence pixel). */
 int ptmi_debug_rng(ptmi_ctx*, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out /* n_pixels*count */);
+/* Compares the kernels' short reciprocal (1 v_rcp + 4 fma, used for Moller-Trumbore's 1/a) with the IEEE quotient for
+ * the `count` consecutive float bit patterns starting at first_bits; reports how many differ and the first one. */
+int ptmi_debug_rcp_check(ptmi_ctx*, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first_bad_bits);
 /* sampleCosineHemisphere (integrator.h:62-85) with explicit (u, v). */
 int ptmi_debug_cosine_sample(ptmi_ctx*, int n, const float* normals, const float* u, const float* v, float* out_dirs);
 
