@@ -77,3 +77,17 @@ def test_workload_counters_match_survey():
     assert abs(st.node_visits / st.rays - 14.0) < 0.3
     assert abs(st.prim_tests / st.rays - 15.5) < 0.3
     assert abs(float(rad.mean()) - 0.1863) < 0.01
+
+
+def test_oracle_reproduces_committed_golden_frames():
+    """tests/golden/frame_*.npz were written by tests/golden/make_golden.py; the oracle must not drift from them."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_*.npz")))
+    assert len(files) >= 5
+    for f in files[:3]:
+        g = np.load(f)
+        o = OracleScene.load(os.path.join(SCENES, str(g["scene"])), int(g["subdivision"]), bool(g["convert_quads"]))
+        rgb, rad, st = o.render(default_camera(), int(g["width"]), int(g["height"]), int(g["spp"]), max_depth=int(g["max_depth"]))
+        assert (rad.view(np.uint32) == g["radiance"].view(np.uint32)).all() and (rgb == g["rgb8"]).all(), f
+        assert [st.samples, st.rays, st.node_visits, st.prim_tests, st.hits] == g["counters"].tolist()

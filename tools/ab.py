@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of ptmi_bounce variants in ONE process (interleaved rounds): traversal mode x segments_per_launch."""
 import itertools, json, os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
 import ptmi
 scene = os.path.join(ROOT, "tests", "golden", "scenes", sys.argv[1] if len(sys.argv) > 1 else "cbox.obj")

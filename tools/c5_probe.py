@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing probe for the 1M-triangle procedural scene (BASELINE.json configs[4]) on one GPU."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
 import numpy as np, ptmi, ptmi_scenes
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

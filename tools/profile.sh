@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles bench.py on the GPU box: kernel trace + stats, then PMC passes (each its own run, no trace domains mixed in).
 set -e
-cd "$GRAFT_REPO_ROOT"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT

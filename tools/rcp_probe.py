@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'cuda-pathtracer_amd/python')
+import sys; sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "cuda-pathtracer_amd", "python"))
 import ptmi, numpy as np
 r = ptmi.Renderer(0)
 # positive floats by exponent: bits = e<<23 .. ; check each binade
