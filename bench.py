@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--side", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: ranks share devices and the gather
+    # goes through host memory with gloo.  Never used for reported numbers.
+    ap.add_argument("--rehearse-gloo", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,17 +106,21 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {n_gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count() if args.rehearse_gloo else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
 
     side = args.side or int(round(BASE_SIDE * math.sqrt(n_gpus)))
     spp = args.spp
 
-    r = ptmi.Renderer(local_rank)
+    r = ptmi.Renderer(device_index)
     r.load_scene(SCENE)
     quads = r.scene_info()["n_quads"] > 0
 
@@ -125,14 +132,18 @@ def main():
     n_local_rows = len(rows)
 
     # gather plumbing (torch = device memory + RCCL only)
-    dev = torch.device("cuda", local_rank)
-    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, dev)
+    dev = torch.device("cuda", device_index)
+    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, torch.device("cpu") if args.rehearse_gloo else dev)
     assert fg.n_local == n_local_rows
 
     def step(stats):
         st = r.render_frame(want_stats=stats)
         if world > 1:
-            r.copy_image_device(fg.send_rgb.data_ptr(), fg.send_rad.data_ptr())
+            if args.rehearse_gloo:
+                rgb, rad = r.read_image()
+                fg.send_rgb[:n_local_rows] = torch.from_numpy(rgb); fg.send_rad[:n_local_rows] = torch.from_numpy(rad)
+            else:
+                r.copy_image_device(fg.send_rgb.data_ptr(), fg.send_rad.data_ptr())
             fg.gather()                              # the single RCCL exchange of a frame
         return st
 
@@ -164,7 +175,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -62,6 +62,7 @@ struct TileMap {              // local row -> global row (ptmi.h: ptmi_tiling)
     int width = 0, height = 0;
     int n_ranks = 1, rank = 0, row_block = 8;
     int local_rows = 0;
+    int tile8 = 0;            // 1: consecutive slots enumerate 8x8 pixel tiles (needs width % 8 == 0 and local_rows % 8 == 0)
 };
 
 struct FrameParams {

@@ -35,9 +35,24 @@ __device__ __forceinline__ float rng_uniform(Rng& r) {
     return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
 }
 
+// slot -> (x, local row).  With tile8 a wave's 64 consecutive slots are an 8x8 pixel tile instead of a 64x1 strip:
+// its camera rays span a smaller solid angle and its bounce rays start closer together, so the wave-synchronous
+// sweep visits a smaller union of nodes and primitives.  Pure scheduling: results are keyed by the pixel.
+__device__ __forceinline__ void slot_to_local(const TileMap& tm, int slot, int& x, int& lr) {
+    if (tm.tile8) {
+        const int tile = slot >> 6, in = slot & 63;
+        const int tiles_per_row = tm.width >> 3;
+        const int ty = tile / tiles_per_row, tx = tile - ty * tiles_per_row;
+        lr = (ty << 3) + (in >> 3);
+        x = (tx << 3) + (in & 7);
+    } else {
+        lr = slot / tm.width;
+        x = slot - lr * tm.width;
+    }
+}
 __device__ __forceinline__ int global_pixel(const TileMap& tm, int slot, int& x, int& y) {
-    const int lr = slot / tm.width;
-    x = slot - lr * tm.width;
+    int lr;
+    slot_to_local(tm, slot, x, lr);
     y = ((lr / tm.row_block) * tm.n_ranks + tm.rank) * tm.row_block + (lr % tm.row_block);
     return y * tm.width + x;
 }
@@ -605,16 +620,19 @@ __global__ __launch_bounds__(kBlock) void ptmi_resolve(TileMap tm, PathState st,
     const int slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= n) return;
     const float4 D = st.D[slot];
+    int ox, olr;
+    slot_to_local(tm, slot, ox, olr);
+    const size_t out = (size_t)olr * (size_t)tm.width + (size_t)ox;      // images are local-row-major whatever the slot order
     const float k = rcp_rn((float)spp);                    // Vector::operator/=(T): T k = 1.0 / t (vector.h:90-94)
     const float c[3] = {D.x * k, D.y * k, D.z * k};
     const float gamma = 1.0f / 2.2f;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        if (radiance) radiance[(size_t)slot * 3 + ch] = c[ch];
+        if (radiance) radiance[out * 3 + ch] = c[ch];
         if (rgb8) {
             const float tm_ = c[ch] / (c[ch] + 1.0f);       // color / (color + 1), component-wise true division
             const float g = ptmi_powf(tm_, gamma);
-            rgb8[(size_t)slot * 3 + ch] = (unsigned char)(255.99f * fminf(g, 1.0f));
+            rgb8[out * 3 + ch] = (unsigned char)(255.99f * fminf(g, 1.0f));
         }
     }
 }

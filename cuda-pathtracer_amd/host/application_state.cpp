@@ -218,6 +218,7 @@ void RenderState::allocateBuffers() {
     tile.width = width; tile.height = height;
     tile.local_rows = countLocalRows(height, tile.n_ranks, tile.rank, tile.row_block);
     n_local = (size_t)tile.local_rows * (size_t)width;
+    tile.tile8 = (allow_tile8 && width % 8 == 0 && tile.local_rows % 8 == 0 && tile.row_block % 8 == 0) ? 1 : 0;
     const size_t n = std::max<size_t>(n_local, 1);
     d_state.A = (float4*)hipMallocSafe(n * sizeof(float4), "state.A");
     d_state.B = (float4*)hipMallocSafe(n * sizeof(float4), "state.B");

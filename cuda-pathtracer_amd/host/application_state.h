@@ -88,6 +88,7 @@ struct RenderState {
     uint64_t seed_base = 2023;
     hipStream_t stream = nullptr;
     size_t n_local = 0;
+    bool allow_tile8 = false;                        // scheduling knob (test/benchmark override)
 
     void allocateBuffers();                          // application_state.h:91-123 (+ render_init)
     void updateResolution(int w, int h, const TileMap* tiling);   // application_state.h:125-129

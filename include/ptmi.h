@@ -68,6 +68,10 @@ typedef struct {
      * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default */
     int      segments_per_launch;
     int      collect_stats;   /* 1: also count rays / node visits / primitive tests (slower build of the kernel) */
+    /* scheduling knob, results are independent of it: which 64 pixels share a wave.  0 = default (64x1 row strips),
+     * 1 = 8x8 pixel tiles (when width and this rank's row count are multiples of 8; measured -1 % with the sweep walk,
+     * +1 % with the per-lane walk).  Takes effect at the next ptmi_update_resolution. */
+    int      wave_tiles;
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).

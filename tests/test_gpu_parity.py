@@ -244,6 +244,21 @@ def test_result_independent_of_segments_per_launch(R):
             assert st.bounce_launches == 1        # megakernel limit: one launch does the whole frame
 
 
+def test_result_independent_of_wave_pixel_layout(R):
+    """64x1 strips per wave (default) vs 8x8 pixel tiles: scheduling only."""
+    R.load_scene(os.path.join(SCENES, "cbox.obj"))
+    out = []
+    for strips in (0, 1):
+        R.set_config(spp=6, max_depth=5, wave_tiles=strips)
+        R.update_resolution(128, 64)
+        R.render_frame()
+        out.append(R.read_image())
+    assert (bits(out[0][1]) == bits(out[1][1])).all() and (out[0][0] == out[1][0]).all()
+    orgb, orad, _ = OracleScene.load(os.path.join(SCENES, "cbox.obj")).render(default_camera(), 128, 64, 6)
+    assert_same_image(out[1][0], out[1][1], orgb, orad, "tile8")
+    R.set_config(wave_tiles=0)
+
+
 def test_rng_state_persists_across_frames(R):
     """No accumulation across frames, only the RNG carries over (integrator.h:379)."""
     W = H = 48
