@@ -139,47 +139,8 @@ __global__ __launch_bounds__(kBlock) void ptmi_frame_begin(TileMap tm, PathState
 // ---------------------------------------------------------------------------------------------
 // primitive tests
 // ---------------------------------------------------------------------------------------------
-// Moller-Trumbore with the reference's accept/reject forms.  edge1/edge2 arrive precomputed.
-// Triangle::intersect (triangle.h:64-96): rejects |a| < eps, u<0||u>1, v<0||u+v>1; accepts t>eps && t>=t_min && t<=t_max.
-__device__ __forceinline__ bool tri_test(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float t_min, float t_max, float& t_out) {
-    const float EPSILON = 1e-8f;
-    const f3 h = cross(d, edge2);
-    const float a = dot(edge1, h);
-    if (fabsf(a) < EPSILON) return false;
-    const float f = rcp_exact_normal(a);                  // == 1.0f / a for every normal a (see pt_vec.h)
-    const f3 s = o - v0;
-    const float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
-    const f3 q = cross(s, edge1);
-    const float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    const float t = f * dot(edge2, q);
-    if (t > EPSILON && t >= t_min && t <= t_max) { t_out = t; return true; }
-    return false;
-}
-// One half of Quad::intersect (quad.h:56-87 / 90-121): note the inclusive forms and the STRICT t < closest.
-__device__ __forceinline__ bool quad_half(f3 v00, f3 edge1, f3 edge2, f3 o, f3 d, float t_min, float& closest_t) {
-    const float EPSILON = 1e-8f;
-    const f3 h = cross(d, edge2);
-    const float a = dot(edge1, h);
-    if (fabsf(a) > EPSILON) {
-        const float f = rcp_exact_normal(a);
-        const f3 s = o - v00;
-        const float u = f * dot(s, h);
-        if (u >= 0.0f && u <= 1.0f) {
-            const f3 q = cross(s, edge1);
-            const float v = f * dot(d, q);
-            if (v >= 0.0f && u + v <= 1.0f) {
-                const float t = f * dot(edge2, q);
-                if (t > EPSILON && t >= t_min && t < closest_t) { closest_t = t; return true; }
-            }
-        }
-    }
-    return false;
-}
-
-// Branch-free accept test for the wave-uniform sweep.  Moller-Trumbore is evaluated exactly as triangle.h:64-96 /
-// quad.h:56-87 write it; the chain of early-outs becomes ONE sign test on a running minimum:
+// Branch-free Moller-Trumbore accept test (edge1/edge2 arrive precomputed), used by all three walks.  The arithmetic
+// is exactly triangle.h:64-96 / quad.h:56-87; the chain of early-outs becomes ONE sign test on a running minimum:
 //   |a| <  eps  reject   <=>  |a| - eps      < 0      (IEEE subtraction never flips a sign; denormals are on)
 //   u   <  0    reject   <=>  u              < 0
 //   u   >  1    reject   <=>  1 - u          < 0
@@ -242,23 +203,25 @@ __device__ __forceinline__ bool box_hit(const float4& n0, const float4& n1, f3 o
     return !(tmax_box < tmin_box);
 }
 
-// Primitive::intersect (primitive.h:83-90) + the closer-hit update of scene.h:89-96 for leaf slot k.
+// Primitive::intersect (primitive.h:83-90) + the closer-hit update of scene.h:89-96 for leaf slot k (per-lane k).
 template <bool HAS_QUADS>
-__device__ __forceinline__ void leaf_prim(const float4* __restrict__ prims, int prim_stride, int k, f3 o, f3 d, float t_min,
-                                          float& closest_t, int& slot_hit, bool& hit_anything) {
+__device__ __forceinline__ void leaf_prim(const float4* __restrict__ prims, int prim_stride, int k, f3 o, f3 d, float t_lo,
+                                          float& closest_t, int& slot_hit) {
     const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+    const float eps = 1e-8f, eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
     float t;
-    bool h;
     if (HAS_QUADS && __float_as_int(p0.w) != 0) {
         const float4 p3 = prims[k * prim_stride + 3];
-        float c = closest_t;                                                  // Quad::intersect starts from t_max = closest_t
-        h = quad_half(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, c);             // (v00, v10, v11)
-        h = quad_half(xyz(p0), xyz(p2), xyz(p3), o, d, t_min, c) || h;        // (v00, v11, v01)
-        t = c;
+        const float t1 = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps_up, t_lo);     // (v00, v10, v11)
+        const float c1 = fminf(t1, closest_t);
+        const float t2 = mt_candidate(xyz(p0), xyz(p2), xyz(p3), o, d, eps_up, t_lo);     // (v00, v11, v01)
+        t = fminf(t2, c1);
     } else {
-        h = tri_test(xyz(p0), xyz(p1), xyz(p2), o, d, t_min, closest_t, t);
+        t = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo);
     }
-    if (h && t < closest_t) { closest_t = t; slot_hit = k; hit_anything = true; }
+    const bool closer = t < closest_t;
+    closest_t = fminf(t, closest_t);
+    slot_hit = closer ? k : slot_hit;
 }
 
 // ---- TRAVERSAL_STACK: Scene::intersect_bvh_optimized (scene.h:50-110) with its explicit stack ------------------
@@ -269,9 +232,10 @@ template <bool HAS_QUADS, bool STATS>
 __device__ __forceinline__ bool intersect_stack(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
                                                 int* stack, bool live, f3 o, f3 d, float t_min, float t_max,
                                                 float& t_hit, int& slot_hit, LaneCounters& cn) {
-    bool hit_anything = false;
     float closest_t = t_max;
+    slot_hit = -1;
     const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    const float t_lo = mt_t_lo(t_min);
     int sp = 0;
     int cur = live ? 0 : -1;
     while (true) {
@@ -288,7 +252,7 @@ __device__ __forceinline__ bool intersect_stack(const float4* __restrict__ nodes
         if (b < 0) {                                       // leaf: -b primitives from slot a
             for (int i = 0; i < -b; i++) {
                 if (STATS) cn.prim_tests++;
-                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
+                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_lo, closest_t, slot_hit);
             }
         } else if (sp < 62) {                              // push right, visit left (= here + 1) next
             stack[(sp++) * kBlock] = b;
@@ -296,7 +260,7 @@ __device__ __forceinline__ bool intersect_stack(const float4* __restrict__ nodes
         }
     }
     t_hit = closest_t;
-    return hit_anything;
+    return slot_hit >= 0;
 }
 
 // ---- TRAVERSAL_LANE: the same walk without a stack ---------------------------------------------------------------
@@ -306,9 +270,10 @@ template <bool HAS_QUADS, bool STATS>
 __device__ __forceinline__ bool intersect_lane(const float4* __restrict__ nodes, const float4* __restrict__ prims, int prim_stride,
                                                int n_nodes, bool live, f3 o, f3 d, float t_min, float t_max,
                                                float& t_hit, int& slot_hit, LaneCounters& cn) {
-    bool hit_anything = false;
     float closest_t = t_max;
+    slot_hit = -1;
     const f3 inv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));
+    const float t_lo = mt_t_lo(t_min);
     int cur = live ? 0 : n_nodes;
     while (cur < n_nodes) {
         const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
@@ -320,13 +285,13 @@ __device__ __forceinline__ bool intersect_lane(const float4* __restrict__ nodes,
         if (pass && b < 0) {
             for (int i = 0; i < -b; i++) {
                 if (STATS) cn.prim_tests++;
-                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_min, closest_t, slot_hit, hit_anything);
+                leaf_prim<HAS_QUADS>(prims, prim_stride, a + i, o, d, t_lo, closest_t, slot_hit);
             }
         }
         cur = next;
     }
     t_hit = closest_t;
-    return hit_anything;
+    return slot_hit >= 0;
 }
 
 // ---- TRAVERSAL_SWEEP: the WAVE walks the node indices once -----------------------------------------------------
@@ -436,8 +401,10 @@ struct BounceArgs {
 };
 
 // LDS: [nodes | prims | mats] when LDS_GEOM (always for SWEEP), then the traversal stacks (STACK only).
+// amdgpu_num_sgpr(80): with <= 80 SGPRs eight 256-thread workgroups fit a CU instead of six
+// (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
 template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
-__global__ __launch_bounds__(kBlock) void ptmi_bounce(BounceArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
     constexpr bool LDS_MATS = LDS_GEOM;
