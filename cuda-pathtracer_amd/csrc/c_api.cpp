@@ -320,7 +320,7 @@ int ptmi_copy_image_device(const ptmi_ctx* c, void* d_rgb8_dst, void* d_radiance
 int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, int* out_mode) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
-        need(force_mode >= -1 && force_mode <= 2, "force_mode must be -1..2");
+        need(force_mode >= -1 && force_mode <= 3, "force_mode must be -1..3");
         need(sweep_max_prims >= 0, "sweep_max_prims must be >= 0");
         SceneState& s = c->app.scene;
         s.force_traversal = force_mode; s.sweep_max_prims = sweep_max_prims;

@@ -51,6 +51,8 @@ enum TraversalMode {
                            // scalar loads (SGPR operands), lanes whose own cursor equals the index take part
     TRAVERSAL_LANE = 1,    // general: every lane walks its own pre-order cursor (stackless, skip pointers)
     TRAVERSAL_STACK = 2,   // trees deeper than 62: explicit LDS stack with the reference's drop rule (scene.h:101-105)
+    TRAVERSAL_PHASED = 3,  // large scenes: the stackless per-lane walk with wave-scheduled phases (ptmi_bounce_phased):
+                           // lanes whose ray ends early shade and start their next segment instead of idling
 };
 
 struct PathState {

@@ -400,110 +400,97 @@ struct BounceArgs {
     StatCounters* stats;
 };
 
-// LDS: [nodes | prims | mats] when LDS_GEOM (always for SWEEP), then the traversal stacks (STACK only).
-// amdgpu_num_sgpr(80): with <= 80 SGPRs eight 256-thread workgroups fit a CU instead of six
-// (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
-template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
-    extern __shared__ float4 smem[];
-    static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
-    constexpr bool LDS_MATS = LDS_GEOM;
-    const int n_node_vec = 2 * a.sc.n_nodes, n_prim_vec = a.sc.prim_stride * a.sc.n_prims, n_mat_vec = 3 * a.sc.n_prims;
-    const float4* __restrict__ nodes = a.sc.nodes; const float4* __restrict__ prims = a.sc.prims; const float4* mats = a.sc.mats;
-    float4* lds = smem;
-    if (LDS_GEOM) {
-        for (int i = threadIdx.x; i < n_node_vec; i += kBlock) lds[i] = a.sc.nodes[i];
-        for (int i = threadIdx.x; i < n_prim_vec; i += kBlock) lds[n_node_vec + i] = a.sc.prims[i];
-        nodes = lds; prims = lds + n_node_vec;
-        lds += n_node_vec + n_prim_vec;
-    }
-    if (LDS_MATS) {
-        for (int i = threadIdx.x; i < n_mat_vec; i += kBlock) lds[i] = a.sc.mats[i];
-        mats = lds;
-        lds += n_mat_vec;
-    }
-    if (LDS_GEOM || LDS_MATS) __syncthreads();
-    int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
+// Per-lane path registers (the 88-byte HBM record, unpacked).
+struct PathRegs {
+    f3 o, d, tp, L, color;
+    Rng rng;
+    unsigned int sample_idx;
+    int depth, px, py;
+};
 
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < a.n_in;
-    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
-    bool alive = active;
+__device__ __forceinline__ void load_path(const PathState& st, const TileMap& tm, int slot, PathRegs& p) {
+    const float4 A = st.A[slot], B = st.B[slot], C = st.C[slot], D = st.D[slot];
+    const uint4 E = st.E[slot]; const uint2 F = st.F[slot];
+    p.o = xyz(A); p.d = xyz(B); p.L = xyz(C); p.color = xyz(D);
+    p.tp = mk3(A.w, B.w, C.w);
+    const unsigned int meta = __float_as_uint(D.w);
+    p.sample_idx = meta >> 8; p.depth = (int)(meta & 0xffu);
+    p.rng = Rng{E.x, E.y, E.z, E.w, F.x, F.y};
+    global_pixel(tm, slot, p.px, p.py);
+}
+__device__ __forceinline__ void store_path(const PathState& st, int slot, const PathRegs& p) {
+    st.A[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.tp.x);
+    st.B[slot] = make_float4(p.d.x, p.d.y, p.d.z, p.tp.y);
+    st.C[slot] = make_float4(p.L.x, p.L.y, p.L.z, p.tp.z);
+    st.D[slot] = make_float4(p.color.x, p.color.y, p.color.z, __uint_as_float((p.sample_idx << 8) | (unsigned int)p.depth));
+    st.E[slot] = make_uint4(p.rng.v0, p.rng.v1, p.rng.v2, p.rng.v3);
+    st.F[slot] = make_uint2(p.rng.v4, p.rng.d);
+}
 
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), tp = mk3(1, 1, 1), L = mk3(0, 0, 0), color = mk3(0, 0, 0);
-    Rng rng = {0, 0, 0, 0, 0, 0};
-    unsigned int meta = 0;
-    int px = 0, py = 0;
-    if (active) {
-        const float4 A = a.st.A[slot], B = a.st.B[slot], C = a.st.C[slot], D = a.st.D[slot];
-        const uint4 E = a.st.E[slot]; const uint2 F = a.st.F[slot];
-        o = xyz(A); d = xyz(B); L = xyz(C); color = xyz(D);
-        tp = mk3(A.w, B.w, C.w);
-        meta = __float_as_uint(D.w);
-        rng = Rng{E.x, E.y, E.z, E.w, F.x, F.y};
-        global_pixel(a.tm, slot, px, py);
-    }
-    unsigned int sample_idx = meta >> 8;
-    int depth = (int)(meta & 0xffu);
-    LaneCounters cn = {0, 0, 0, 0};
-
-    for (int seg = 0; seg < a.segments; seg++) {
-        if (!__any(alive)) break;
-        // the whole wave enters the traversal together (finished lanes ride along masked): required by SWEEP
-        float t = 0.0f; int k = -1;
-        if (STATS && alive) cn.rays++;
-        const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
-                                                               o, d, 1e-4f, FLT_MAX, t, k, cn);
-        if (alive) {
-            bool end_sample = !hit;                                                   // integrator.h:198-201
-            if (hit) {
-                if (STATS) cn.hits++;
-                const f3 n = xyz(mats[3 * k]), bsdf = xyz(mats[3 * k + 1]), Le = xyz(mats[3 * k + 2]);
-                const f3 p = o + t * d;                                               // triangle.h:90
-                L = L + tp * Le;                                                      // integrator.h:204
-                if (depth > 2) {                                                      // integrator.h:207-212
-                    const float max_tp = fmaxf(tp.x, fmaxf(tp.y, tp.z));
-                    const float rr_prob = fminf(max_tp, 0.95f);
-                    if (rng_uniform(rng) > rr_prob) end_sample = true;
-                    else tp = div_scalar(tp, rr_prob);
-                }
-                if (!end_sample) {
-                    tp = tp * bsdf;                                                   // integrator.h:215
-                    if (length(tp) < 1e-5f) end_sample = true;                        // integrator.h:218
-                    else {
-                        const f3 sn = dot(d, n) < 0 ? n : -n;                         // integrator.h:221-222
-                        const float u = rng_uniform(rng);                             // integrator.h:63-64
-                        const float v = rng_uniform(rng);
-                        depth++;
-                        if (depth < a.fp.max_depth) {
-                            const f3 next = cosine_hemisphere(sn, u, v);              // integrator.h:230
-                            o = p + 1e-4f * sn;                                       // integrator.h:266
-                            d = unit_vector(next);                                    // Ray ctor normalises again
-                        } else end_sample = true;                                     // loop bound; the draws above are still consumed
-                    }
-                }
-            }
-            if (end_sample) {
-                color = color + L;                                                    // integrator.h:390
-                sample_idx++;
-                if (sample_idx < (unsigned int)a.fp.spp) {                            // next iteration of the spp loop
-                    camera_ray(a.fp, a.tm, px, py, rng, o, d);
-                    tp = mk3(1.0f, 1.0f, 1.0f); L = mk3(0.0f, 0.0f, 0.0f); depth = 0;
-                } else alive = false;
+// One iteration of integrator()'s depth loop after the intersection (integrator.h:198-266), plus the end of the
+// sample and the head of the next spp iteration (integrator.h:383-390) when the path ends.
+// Returns true while the pixel still has a ray to trace; false once all spp samples are done.
+template <bool STATS>
+__device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const float4* mats, PathRegs& p,
+                                           bool hit, float t, int k, LaneCounters& cn) {
+    bool end_sample = !hit;                                                       // integrator.h:198-201
+    if (hit) {
+        if (STATS) cn.hits++;
+        const f3 n = xyz(mats[3 * k]), bsdf = xyz(mats[3 * k + 1]), Le = xyz(mats[3 * k + 2]);
+        const f3 hp = p.o + t * p.d;                                              // triangle.h:90
+        p.L = p.L + p.tp * Le;                                                    // integrator.h:204
+        if (p.depth > 2) {                                                        // integrator.h:207-212
+            const float max_tp = fmaxf(p.tp.x, fmaxf(p.tp.y, p.tp.z));
+            const float rr_prob = fminf(max_tp, 0.95f);
+            if (rng_uniform(p.rng) > rr_prob) end_sample = true;
+            else p.tp = div_scalar(p.tp, rr_prob);
+        }
+        if (!end_sample) {
+            p.tp = p.tp * bsdf;                                                   // integrator.h:215
+            if (length(p.tp) < 1e-5f) end_sample = true;                          // integrator.h:218
+            else {
+                const f3 sn = dot(p.d, n) < 0 ? n : -n;                           // integrator.h:221-222
+                const float u = rng_uniform(p.rng);                               // integrator.h:63-64
+                const float v = rng_uniform(p.rng);
+                p.depth++;
+                if (p.depth < fp.max_depth) {
+                    const f3 next = cosine_hemisphere(sn, u, v);                  // integrator.h:230
+                    p.o = hp + 1e-4f * sn;                                        // integrator.h:266
+                    p.d = unit_vector(next);                                      // Ray ctor normalises again
+                } else end_sample = true;                                         // loop bound; the draws above are still consumed
             }
         }
     }
-
-    if (active) {
-        a.st.A[slot] = make_float4(o.x, o.y, o.z, tp.x);
-        a.st.B[slot] = make_float4(d.x, d.y, d.z, tp.y);
-        a.st.C[slot] = make_float4(L.x, L.y, L.z, tp.z);
-        a.st.D[slot] = make_float4(color.x, color.y, color.z, __uint_as_float((sample_idx << 8) | (unsigned int)depth));
-        a.st.E[slot] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);
-        a.st.F[slot] = make_uint2(rng.v4, rng.d);
+    if (end_sample) {
+        p.color = p.color + p.L;                                                  // integrator.h:390
+        p.sample_idx++;
+        if (p.sample_idx >= (unsigned int)fp.spp) return false;
+        camera_ray(fp, tm, p.px, p.py, p.rng, p.o, p.d);                          // next iteration of the spp loop
+        p.tp = mk3(1.0f, 1.0f, 1.0f); p.L = mk3(0.0f, 0.0f, 0.0f); p.depth = 0;
     }
+    return true;
+}
 
-    // active-path compaction: one atomic per wave reserves queue space, lanes scatter by prefix popcount
+// stage the scene into LDS (when LDS_GEOM) and return the LDS cursor after it
+template <bool LDS_GEOM>
+__device__ __forceinline__ float4* stage_scene(const DeviceScene& sc, float4* lds, const float4*& nodes, const float4*& prims, const float4*& mats) {
+    nodes = sc.nodes; prims = sc.prims; mats = sc.mats;
+    if (LDS_GEOM) {
+        const int n_node_vec = 2 * sc.n_nodes, n_prim_vec = sc.prim_stride * sc.n_prims, n_mat_vec = 3 * sc.n_prims;
+        for (int i = threadIdx.x; i < n_node_vec; i += kBlock) lds[i] = sc.nodes[i];
+        for (int i = threadIdx.x; i < n_prim_vec; i += kBlock) lds[n_node_vec + i] = sc.prims[i];
+        for (int i = threadIdx.x; i < n_mat_vec; i += kBlock) lds[n_node_vec + n_prim_vec + i] = sc.mats[i];
+        nodes = lds; prims = lds + n_node_vec; mats = lds + n_node_vec + n_prim_vec;
+        lds += n_node_vec + n_prim_vec + n_mat_vec;
+        __syncthreads();
+    }
+    return lds;
+}
+
+// kernel tail shared by both bounce kernels: active-path compaction (one atomic per wave reserves queue space, lanes
+// scatter by prefix popcount) and the optional workload counters
+template <bool STATS>
+__device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, int slot, const LaneCounters& cn) {
     {
         const unsigned long long mask = __ballot(alive);
         const int lane = threadIdx.x & 63;
@@ -512,7 +499,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
         base = __shfl(base, 0);
         if (alive) a.queue_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
     }
-
     if (STATS) {
         unsigned long long r = cn.rays, nv = cn.node_visits, pt = cn.prim_tests, h = cn.hits;
         for (int off = 32; off > 0; off >>= 1) {
@@ -523,6 +509,125 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
             atomicAdd(&a.stats->prim_tests, pt); atomicAdd(&a.stats->hits, h);
         }
     }
+}
+
+// ---- ptmi_bounce: segment-synchronous form (SWEEP and STACK walks) ------------------------------------------------
+// Every wave traces one ray segment per lane, then shades, K times.  LDS: [nodes | prims | mats] when LDS_GEOM (always
+// for SWEEP), then the traversal stacks (STACK only).
+// amdgpu_num_sgpr(80): with <= 80 SGPRs eight 256-thread workgroups fit a CU instead of six
+// (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
+template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
+    extern __shared__ float4 smem[];
+    static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
+    const float4 *nodes, *prims, *mats;
+    float4* lds = stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
+    int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
+
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < a.n_in;
+    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
+    bool alive = active;
+    PathRegs p = {};
+    if (active) load_path(a.st, a.tm, slot, p);
+    LaneCounters cn = {0, 0, 0, 0};
+
+    for (int seg = 0; seg < a.segments; seg++) {
+        if (!__any(alive)) break;
+        // the whole wave enters the traversal together (finished lanes ride along masked): required by SWEEP
+        float t = 0.0f; int k = -1;
+        if (STATS && alive) cn.rays++;
+        const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
+                                                               p.o, p.d, 1e-4f, FLT_MAX, t, k, cn);
+        if (alive) alive = shade_step<STATS>(a.fp, a.tm, mats, p, hit, t, k, cn);
+    }
+
+    if (active) store_path(a.st, slot, p);
+    finish_launch<STATS>(a, alive, slot, cn);
+}
+
+// ---- ptmi_bounce_phased: wave-scheduled phases (LANE walk for large scenes) -----------------------------------------
+// A lane is always in one of three phases: NODE (next pre-order node to visit), PRIM (pending primitives of a leaf whose
+// box it hit) or SHADE (traversal finished).  Every iteration the WAVE executes the one phase that most of its lanes
+// are waiting for.  A lane whose ray ends early shades and starts its next segment while its neighbours are still
+// walking the tree, instead of idling until the longest ray of the wave is done (segment-synchronous per-lane walk on
+// the 1M-triangle scene: 13.8 % VALU lane utilisation).  Per lane the sequence of node visits, primitive tests and RNG
+// draws is exactly the reference's; only the interleaving between lanes changes.
+#ifndef PTMI_NODE_BURST
+#define PTMI_NODE_BURST 3
+#endif
+template <bool LDS_GEOM, bool HAS_QUADS, bool STATS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
+    extern __shared__ float4 smem[];
+    const float4 *nodes, *prims, *mats;
+    stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
+
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < a.n_in;
+    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
+    bool alive = active;
+    PathRegs p = {};
+    if (active) load_path(a.st, a.tm, slot, p);
+    LaneCounters cn = {0, 0, 0, 0};
+
+    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
+    const int n_nodes = a.sc.n_nodes, prim_stride = a.sc.prim_stride;
+    const float t_min = 1e-4f, t_lo = mt_t_lo(t_min);
+    int phase = alive ? PH_NODE : PH_DONE;
+    int segs_left = a.segments;
+    int cur = 0, pk = 0, pend = 0, slot_hit = -1;
+    float closest_t = FLT_MAX;
+    f3 inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));
+    if (STATS && alive) cn.rays++;
+
+    while (true) {
+        const int c_node = __popcll(__ballot(phase == PH_NODE));
+        const int c_prim = __popcll(__ballot(phase == PH_PRIM));
+        const int c_shade = __popcll(__ballot(phase == PH_SHADE));
+        if (c_node + c_prim + c_shade == 0) break;
+        if (c_node >= c_prim && c_node >= c_shade) {
+            // a short burst of node steps per scheduling decision: in large scenes a ray visits ~10 nodes between two
+            // leaves, and the three ballots + branches of a decision cost about as much as a node test
+#pragma unroll
+            for (int burst = 0; burst < PTMI_NODE_BURST; burst++) {
+                if (phase == PH_NODE) {                                // one node of Scene::intersect_bvh_optimized (scene.h:63-106)
+                    const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+                    if (STATS) cn.node_visits++;
+                    const int na = __float_as_int(n0.w), nb = __float_as_int(n1.w);
+                    const bool pass = box_hit(n0, n1, p.o, inv, t_min, closest_t);
+                    int next = cur + 1;
+                    if (nb < 0) {
+                        if (pass) { pk = na; pend = na - nb; phase = PH_PRIM; }
+                    } else if (!pass) next = na;
+                    cur = next;
+                    if (phase == PH_NODE && cur >= n_nodes) phase = PH_SHADE;
+                }
+            }
+        } else if (c_prim >= c_shade) {
+            if (phase == PH_PRIM) {                                    // one primitive of the leaf loop (scene.h:85-99)
+                if (STATS) cn.prim_tests++;
+                leaf_prim<HAS_QUADS>(prims, prim_stride, pk, p.o, p.d, t_lo, closest_t, slot_hit);
+                pk++;
+                if (pk == pend) phase = cur >= n_nodes ? PH_SHADE : PH_NODE;
+            }
+        } else {
+            if (phase == PH_SHADE) {
+                const bool more = shade_step<STATS>(a.fp, a.tm, mats, p, slot_hit >= 0, closest_t, slot_hit, cn);
+                segs_left--;
+                if (!more) { alive = false; phase = PH_DONE; }
+                else if (segs_left == 0) phase = PH_DONE;              // state goes back to HBM with the next ray ready
+                else {
+                    cur = 0; slot_hit = -1; closest_t = FLT_MAX;
+                    inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));
+                    phase = PH_NODE;
+                    if (STATS) cn.rays++;
+                }
+            }
+        }
+    }
+
+    if (active) store_path(a.st, slot, p);
+    finish_launch<STATS>(a, alive, slot, cn);
 }
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
@@ -550,7 +655,18 @@ static void launch_qs(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s)
 template <int MODE>
 static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     if (MODE == TRAVERSAL_SWEEP || a.sc.lds_resident) launch_qs<MODE, true>(a, grid, lds, s);
-    else if (MODE != TRAVERSAL_SWEEP) launch_qs<MODE == TRAVERSAL_SWEEP ? TRAVERSAL_LANE : MODE, false>(a, grid, lds, s);
+    else if (MODE != TRAVERSAL_SWEEP) launch_qs<MODE == TRAVERSAL_SWEEP ? TRAVERSAL_STACK : MODE, false>(a, grid, lds, s);
+}
+template <bool G_>
+static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
+    const dim3 block(kBlock);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<G_, false, false>), grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<G_, false, true>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<G_, true, false>), grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL((ptmi_bounce_phased<G_, true, true>), grid, block, lds, s, a); break;
+    }
 }
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
@@ -562,6 +678,7 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
     const size_t lds = bounce_lds_bytes(sc);
     if (sc.traversal == TRAVERSAL_SWEEP) launch_bounce_mode<TRAVERSAL_SWEEP>(a, grid, lds, s);
     else if (sc.traversal == TRAVERSAL_LANE) launch_bounce_mode<TRAVERSAL_LANE>(a, grid, lds, s);
+    else if (sc.traversal == TRAVERSAL_PHASED) { if (sc.lds_resident) launch_phased<true>(a, grid, lds, s); else launch_phased<false>(a, grid, lds, s); }
     else launch_bounce_mode<TRAVERSAL_STACK>(a, grid, lds, s);
 }
 
@@ -641,7 +758,8 @@ void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const 
     const size_t lds = (size_t)sc.stack_entries * kBlock * sizeof(int);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
 #define PTMI_DBG(M_, Q_) hipLaunchKernelGGL((ptmi_debug_intersect_k<M_, Q_>), grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm)
-    switch (sc.traversal * 2 + (sc.has_quads ? 1 : 0)) {
+    const int walk = sc.traversal == TRAVERSAL_PHASED ? TRAVERSAL_LANE : sc.traversal;   // the phased kernel walks like LANE
+    switch (walk * 2 + (sc.has_quads ? 1 : 0)) {
         case 0: PTMI_DBG(TRAVERSAL_SWEEP, false); break;
         case 1: PTMI_DBG(TRAVERSAL_SWEEP, true); break;
         case 2: PTMI_DBG(TRAVERSAL_LANE, false); break;

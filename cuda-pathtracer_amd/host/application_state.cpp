@@ -195,7 +195,8 @@ void SceneState::chooseTraversal() {
     if (!d_nodes) return;
     if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
-    else d_scene.traversal = TRAVERSAL_LANE;
+    else if (d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;     // short walks: segment-synchronous is cheaper
+    else d_scene.traversal = TRAVERSAL_PHASED;                             // long, divergent walks through L2/MALL/HBM
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
     if (d_scene.traversal == TRAVERSAL_SWEEP && !d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;   // the sweep reads through LDS
 }

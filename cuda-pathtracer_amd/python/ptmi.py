@@ -289,7 +289,7 @@ class Renderer:
         self._ck(self.L.ptmi_copy_image_device(self.h, d_rgb8_ptr, d_radiance_ptr))
 
     # --- test hooks ---
-    SWEEP, LANE, STACK = 0, 1, 2
+    SWEEP, LANE, STACK, PHASED = 0, 1, 2, 3
 
     def set_traversal(self, force_mode=-1, sweep_max_prims=64):
         """Returns the traversal mode in effect for the loaded scene (-1 if none)."""

@@ -167,7 +167,8 @@ int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows,
 
 /* ---- unit-test hooks: single stages of the path on the device ------------- */
 /* Overrides how ptmi_bounce walks the BVH (results are identical in every mode): force_mode -1 = automatic,
- * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack; sweep_max_prims = largest scene (primitives)
+ * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases;
+ * sweep_max_prims = largest scene (primitives)
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
 int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int* out_mode);

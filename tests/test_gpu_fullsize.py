@@ -53,7 +53,7 @@ def test_config2_cbox_1024_256spp_depth8_whole_frame(R):
     assert st.samples == W * H * spp
     # properties on the same full-size frame: scheduling knob, traversal mode, 8-way tiling
     R.set_config(collect_stats=False)
-    for seg, mode in ((1, -1), (100000, -1), (8, ptmi.Renderer.LANE)):
+    for seg, mode in ((1, -1), (100000, -1), (8, ptmi.Renderer.LANE), (32, ptmi.Renderer.PHASED)):
         R.set_traversal(mode); R.update_resolution(W, H); R.set_config(segments_per_launch=seg)
         R.render_frame()
         rgb2, rad2 = R.read_image()
@@ -117,7 +117,7 @@ def test_config5_one_million_triangles_2048_2048spp(R):
     assert len(sc["type"]) == 1048576
     args = (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
     R.load_scene_arrays(*args)
-    assert R.scene_info()["n_prims"] == 1048576 and R.set_traversal(-1) == R.LANE
+    assert R.scene_info()["n_prims"] == 1048576 and R.set_traversal(-1) == R.PHASED
     o = OracleScene.from_arrays(*args)
     # rank 3 of 8 at FULL spp (one GPU's share of the 8-GPU configuration): 1/8 of 8.6 G samples
     R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=False)

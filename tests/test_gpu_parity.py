@@ -156,10 +156,11 @@ def test_frame_matches_oracle(R, name, sub, conv, W, H, spp, depth):
            (ost.samples, ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("name,sub,conv", [("cbox.obj", 0, False), ("cbox_quads.obj", 0, False), ("cbox.obj", 1, False)])
 def test_every_traversal_mode_gives_the_same_frame(R, mode, name, sub, conv):
-    """SWEEP (wave-uniform), LANE (stackless per lane) and STACK (explicit stack) must agree bit for bit."""
+    """SWEEP (wave-uniform), LANE (stackless per lane), STACK (explicit stack) and PHASED (wave-scheduled phases)
+    must agree bit for bit."""
     path = os.path.join(SCENES, name)
     R.load_scene(path, sub, conv)
     assert R.set_traversal(mode) == mode
