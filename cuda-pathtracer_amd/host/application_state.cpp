@@ -195,8 +195,8 @@ void SceneState::chooseTraversal() {
     if (!d_nodes) return;
     if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
-    else if (d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;     // short walks: segment-synchronous is cheaper
-    else d_scene.traversal = TRAVERSAL_PHASED;                             // long, divergent walks through L2/MALL/HBM
+    else d_scene.traversal = TRAVERSAL_PHASED;   // measured faster than the segment-synchronous LANE walk from 128 primitives up
+                                                 // (LDS-resident or not); LANE stays available through the override
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
     if (d_scene.traversal == TRAVERSAL_SWEEP && !d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;   // the sweep reads through LDS
 }
@@ -334,6 +334,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         if (stats) PTMI_HIP(hipEventRecord(e0, s));
         launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, q_in, n_active, r.d_queue[cur], r.d_count, segments,
                       want_stats ? r.d_stats : nullptr, s);
+        PTMI_HIP(hipGetLastError());                   // launch-time failures (bad LDS size, ...) surface here, not a frame later
         const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
         if (stats) PTMI_HIP(hipEventRecord(e1, s));
         PTMI_HIP(hipMemcpyAsync(r.h_count, r.d_count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -133,8 +133,9 @@ FRAMES = [  # scene, sub, conv, W, H, spp, max_depth
     ("cbox.obj", 0, False, 96, 64, 8, 8),
     ("cbox_quads.obj", 0, False, 128, 72, 16, 5),
     ("cbox_quads.obj", 0, True, 64, 64, 8, 8),
-    ("cbox.obj", 2, False, 64, 64, 8, 5),         # 512 triangles: still LDS-resident
-    ("cbox_quads.obj", 3, False, 64, 64, 4, 5),   # 1024 quads: HBM/L2 scene path
+    ("cbox.obj", 1, False, 64, 64, 8, 5),         # 128 triangles: PHASED walk, scene LDS-resident
+    ("cbox.obj", 2, False, 64, 64, 8, 5),         # 512 triangles: PHASED walk from L2
+    ("cbox_quads.obj", 3, False, 64, 64, 4, 5),   # 1024 quads: PHASED walk from L2
     ("cbox.obj", 0, False, 33, 17, 3, 1),         # ragged size, depth 1
     ("cbox.obj", 0, False, 1, 1, 5, 5),           # single pixel
 ]

@@ -150,3 +150,32 @@ def test_constructor_normals_bit_exact():
         v = np.ascontiguousarray(p["verts"][i])
         L.ref_quad_geometric_normal(v[0].ctypes.data, v[1].ctypes.data, v[2].ctypes.data, v[3].ctypes.data, out.ctypes.data)
         assert (bits(out) == bits(p["normal"][i])).all(), i
+
+
+def test_large_tessellated_scene_bvh_and_intersect():
+    """65,536 displaced triangles (the 1 M-triangle stress scene at 1/16 density): the reference's BVHBuilder and
+    Scene::intersect on its 4364-byte Primitive records vs the oracle, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-pathtracer_amd", "python"))
+    import ptmi_scenes
+    base = OracleScene.load(SCENES + "/cbox_quads.obj").prims()
+    sc = ptmi_scenes.tessellated_cornell(base, 64, 32, seed=1)
+    assert len(sc["type"]) == 65536
+    args = (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
+    o = OracleScene.from_arrays(*args); r = RefScene(*args)
+    bo, br = o.bvh(), r.bvh()
+    assert len(bo["left"]) == len(br["left"])
+    for k in ("left", "count", "indices"):
+        assert (bo[k] == br[k]).all(), k
+    assert (bits(bo["bmin"]) == bits(br["bmin"])).all() and (bits(bo["bmax"]) == bits(br["bmax"])).all()
+    O, D = _rays_for(o, np.random.default_rng(21), 1200)
+    rh = r.intersect(O, D)
+    hits = 0
+    for i in range(len(O)):
+        oh = o.intersect(O[i], D[i])
+        assert oh.hit == rh[i].hit and oh.prim == rh[i].prim, i
+        if oh.hit:
+            hits += 1
+            assert F(oh.t).view(np.uint32) == F(rh[i].t).view(np.uint32)
+    assert hits > 300
