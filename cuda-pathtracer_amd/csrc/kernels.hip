@@ -139,6 +139,15 @@ __global__ __launch_bounds__(kBlock) void ptmi_frame_begin(TileMap tm, PathState
 // ---------------------------------------------------------------------------------------------
 // primitive tests
 // ---------------------------------------------------------------------------------------------
+// fminf/fmaxf without the v_max_f32 x, x, x "canonicalize" the compiler puts in front of every min/max whose operand
+// it cannot prove free of signalling NaNs (loop-carried closest_t, values loaded from LDS).  v_min/v_max/v_min3 return
+// the other operand for a quiet NaN, exactly like fminf/fmaxf; they differ only for signalling NaNs, which no
+// arithmetic instruction ever produces and the scene loader never stores.  Each avoided canonicalize is a half-rate op.
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // Branch-free Moller-Trumbore accept test (edge1/edge2 arrive precomputed), used by all three walks.  The arithmetic
 // is exactly triangle.h:64-96 / quad.h:56-87; the chain of early-outs becomes ONE sign test on a running minimum:
 //   |a| <  eps  reject   <=>  |a| - eps      < 0      (IEEE subtraction never flips a sign; denormals are on)
@@ -160,14 +169,30 @@ __device__ __forceinline__ float mt_candidate(f3 v0, f3 edge1, f3 edge2, f3 o, f
     const float u = f * dot(s, h);
     // wave-level early-out: if the (a, u) tests already reject every lane that is testing this primitive, the second
     // half of Moller-Trumbore is skipped for the whole wave (coherent camera-ray waves do this for most primitives)
-    const float m1 = fminf(fminf(fabsf(a) - eps_for_a, u), 1.0f - u);
+    const float m1 = min3_raw(fabsf(a) - eps_for_a, u, 1.0f - u);
     if (!__any(m1 >= 0.0f)) return __builtin_inff();
     const f3 q = cross(s, edge1);
     const float v = f * dot(d, q);
     const float t = f * dot(edge2, q);
-    float m = fminf(fminf(m1, v), 1.0f - (u + v));
-    m = fminf(m, t - t_lo);
+    float m = min3_raw(m1, v, 1.0f - (u + v));
+    m = min_raw(m, t - t_lo);
     return (m >= 0.0f) ? t : __builtin_inff();
+}
+// Triangle form: accept flag and t separately, so that the caller needs no +inf select (one half-rate op less)
+__device__ __forceinline__ bool mt_accept(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float eps_for_a, float t_lo, float closest_t, float& t) {
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = rcp_exact_normal(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const float m1 = min3_raw(fabsf(a) - eps_for_a, u, 1.0f - u);
+    if (!__any(m1 >= 0.0f)) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    t = f * dot(edge2, q);
+    float m = min3_raw(m1, v, 1.0f - (u + v));
+    m = min_raw(m, t - t_lo);
+    return (m >= 0.0f) & (t < closest_t);          // t <= t_max && scene.h:90's strict t < closest_t; false for a NaN t
 }
 // t_lo for a given t_min:  t > 1e-8f && t >= t_min  <=>  t >= t_lo
 __device__ __forceinline__ float mt_t_lo(float t_min) {
@@ -184,22 +209,15 @@ struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits; };
 // tmax_box are never NaN (a NaN t0/t1 - 0 * inf - is ignored by both forms) and the sign of a zero cannot reach the
 // final comparison.  One v_max/v_min instead of v_cmp + v_cndmask (all of them half-rate VALU ops on gfx950).
 __device__ __forceinline__ bool box_hit(const float4& n0, const float4& n1, f3 o, f3 inv, float t_min, float closest_t) {
-    float tmin_box = t_min, tmax_box = closest_t;
-    {
-        float t0 = (n0.x - o.x) * inv.x, t1 = (n1.x - o.x) * inv.x;
-        if (inv.x < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
-    }
-    {
-        float t0 = (n0.y - o.y) * inv.y, t1 = (n1.y - o.y) * inv.y;
-        if (inv.y < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
-    }
-    {
-        float t0 = (n0.z - o.z) * inv.z, t1 = (n1.z - o.z) * inv.z;
-        if (inv.z < 0.0f) { const float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin_box = fmaxf(t0, tmin_box); tmax_box = fminf(t1, tmax_box);
-    }
+    float t0x = (n0.x - o.x) * inv.x, t1x = (n1.x - o.x) * inv.x;
+    if (inv.x < 0.0f) { const float tmp = t0x; t0x = t1x; t1x = tmp; }
+    float t0y = (n0.y - o.y) * inv.y, t1y = (n1.y - o.y) * inv.y;
+    if (inv.y < 0.0f) { const float tmp = t0y; t0y = t1y; t1y = tmp; }
+    float t0z = (n0.z - o.z) * inv.z, t1z = (n1.z - o.z) * inv.z;
+    if (inv.z < 0.0f) { const float tmp = t0z; t0z = t1z; t1z = tmp; }
+    // max/min are associative and NaN-ignoring, so folding the three axes in one max3/min3 keeps the reference's result
+    const float tmin_box = max3_raw(max_raw(t0x, t_min), t0y, t0z);
+    const float tmax_box = min3_raw(min_raw(t1x, closest_t), t1y, t1z);
     return !(tmax_box < tmin_box);
 }
 
@@ -213,14 +231,18 @@ __device__ __forceinline__ void leaf_prim(const float4* __restrict__ prims, int 
     if (HAS_QUADS && __float_as_int(p0.w) != 0) {
         const float4 p3 = prims[k * prim_stride + 3];
         const float t1 = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps_up, t_lo);     // (v00, v10, v11)
-        const float c1 = fminf(t1, closest_t);
+        const float c1 = min_raw(t1, closest_t);
         const float t2 = mt_candidate(xyz(p0), xyz(p2), xyz(p3), o, d, eps_up, t_lo);     // (v00, v11, v01)
-        t = fminf(t2, c1);
+        t = min_raw(t2, c1);
     } else {
-        t = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo);
+        float tt = 0.0f;
+        const bool acc = mt_accept(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo, closest_t, tt);
+        closest_t = acc ? tt : closest_t;
+        slot_hit = acc ? k : slot_hit;
+        return;
     }
     const bool closer = t < closest_t;
-    closest_t = fminf(t, closest_t);
+    closest_t = min_raw(t, closest_t);
     slot_hit = closer ? k : slot_hit;
 }
 
@@ -313,14 +335,18 @@ __device__ __forceinline__ void leaf_prim_uniform(const float4* prims, int prim_
         const float4 p3 = prims[k * prim_stride + 3];
         // Quad::intersect: closest = t_max (= closest_t); each half accepts t < closest, second half sees the first's result
         const float t1 = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps_up, t_lo);     // (v00, v10, v11), |a| > eps
-        const float c1 = fminf(t1, closest_t);
+        const float c1 = min_raw(t1, closest_t);
         const float t2 = mt_candidate(xyz(p0), xyz(p2), xyz(p3), o, d, eps_up, t_lo);     // (v00, v11, v01)
-        t = fminf(t2, c1);                        // == closest_t when neither half was accepted
+        t = min_raw(t2, c1);                        // == closest_t when neither half was accepted
     } else {
-        t = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo);                     // !(|a| < eps)
+        float tt = 0.0f;                                                                  // !(|a| < eps)
+        const bool acc = mt_accept(xyz(p0), xyz(p1), xyz(p2), o, d, eps, t_lo, closest_t, tt);
+        closest_t = acc ? tt : closest_t;
+        slot_hit = acc ? k : slot_hit;
+        return;
     }
-    const bool closer = t < closest_t;            // tri: t <= t_max && t < closest_t ; quad: hit && temp.t < closest_t (scene.h:89-90)
-    closest_t = fminf(t, closest_t);
+    const bool closer = t < closest_t;            // quad: hit && temp.t < closest_t (scene.h:89-90)
+    closest_t = min_raw(t, closest_t);
     slot_hit = closer ? k : slot_hit;
 }
 
