@@ -145,6 +145,8 @@ def main():
             else:
                 r.copy_image_device(fg.send_rgb.data_ptr(), fg.send_rad.data_ptr())
             fg.gather()                              # the single RCCL exchange of a frame
+            if not args.rehearse_gloo:
+                torch.cuda.current_stream().synchronize()   # the send buffer is reused by the next frame
         return st
 
     def barrier():

@@ -20,4 +20,6 @@ def _built():
     import subprocess
     if not os.path.exists(os.path.join(ROOT, "oracle", "libptmi_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if not os.path.exists(os.path.join(ROOT, "cuda-pathtracer_amd", "libptmi.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cuda-pathtracer_amd"), "-j4"])   # hipcc cross-compiles gfx950 anywhere
     yield
