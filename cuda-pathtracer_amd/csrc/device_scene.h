@@ -84,9 +84,11 @@ void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* 
 void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParams& fp, hipStream_t s);
 // The hot kernel: advances every queued path by up to `segments` ray segments, regenerating camera rays when a
 // sample ends; appends still-unfinished pixels to queue_out (wave ballot + prefix popcount, one atomic per wave).
-// queue_in == nullptr means "all local pixels" (identity queue); n_in is then the pixel count.
+// queue_in == nullptr means "all local pixels" (identity queue); n_in is then the pixel count.  count_in (device
+// pointer, may be nullptr) holds the exact length of queue_in when the host only knows the upper bound n_in: the
+// host can then enqueue launches ahead of the counts coming back.
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
-                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
+                   const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */, hipStream_t s);
 // mean, Reinhard, gamma, 8-bit (integrator.h:393-407) + float radiance.
 void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s);

@@ -420,7 +420,8 @@ __device__ __forceinline__ f3 cosine_hemisphere(f3 n, float u, float v) {
 // ---------------------------------------------------------------------------------------------
 struct BounceArgs {
     DeviceScene sc; TileMap tm; PathState st; FrameParams fp;
-    const int* queue_in; int n_in;
+    const int* queue_in; int n_in;          // n_in: upper bound known to the host (sizes the grid)
+    const int* count_in;                    // device-side exact count of queue_in (nullptr: n_in is exact)
     int* queue_out; int* count_out;
     int segments;
     StatCounters* stats;
@@ -546,12 +547,14 @@ template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
+    const int n_in = a.count_in ? *a.count_in : a.n_in;
+    if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
     const float4 *nodes, *prims, *mats;
     float4* lds = stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
     int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < a.n_in;
+    const bool active = idx < n_in;
     const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
     bool alive = active;
     PathRegs p = {};
@@ -585,11 +588,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
 template <bool LDS_GEOM, bool HAS_QUADS, bool STATS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
     extern __shared__ float4 smem[];
+    const int n_in = a.count_in ? *a.count_in : a.n_in;
+    if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
     const float4 *nodes, *prims, *mats;
     stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < a.n_in;
+    const bool active = idx < n_in;
     const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
     bool alive = active;
     PathRegs p = {};
@@ -696,10 +701,10 @@ static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_
 }
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
-                   const int* queue_in, int n_in, int* queue_out, int* count_out, int segments,
+                   const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats, hipStream_t s) {
     if (n_in <= 0) return;
-    BounceArgs a{sc, tm, st, fp, queue_in, n_in, queue_out, count_out, segments, stats};
+    BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats};
     const dim3 grid((n_in + kBlock - 1) / kBlock);
     const size_t lds = bounce_lds_bytes(sc);
     if (sc.traversal == TRAVERSAL_SWEEP) launch_bounce_mode<TRAVERSAL_SWEEP>(a, grid, lds, s);

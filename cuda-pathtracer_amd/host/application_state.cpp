@@ -231,9 +231,9 @@ void RenderState::allocateBuffers() {
     d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
     d_queue[0] = (int*)hipMallocSafe(n * sizeof(int), "d_queue0");
     d_queue[1] = (int*)hipMallocSafe(n * sizeof(int), "d_queue1");
-    d_count = (int*)hipMallocSafe(2 * sizeof(int), "d_count");
+    d_count = (int*)hipMallocSafe(8 * sizeof(int), "d_count");
     d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
-    PTMI_HIP(hipHostMalloc((void**)&h_count, 2 * sizeof(int)));
+    PTMI_HIP(hipHostMalloc((void**)&h_count, 8 * sizeof(int)));
 
     // camera: image size + aspect, then updateCamera (application_state.h:106-109)
     h_camera.image_width = width; h_camera.image_height = height;
@@ -306,6 +306,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
 
     const int n_local = (int)r.n_local;
+    int last_out = 0;                                  // output count of the most recently retired launch
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
     hipStream_t s = r.stream;
     const bool want_stats = g.config.collect_stats;
@@ -321,28 +322,45 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
 
     launch_frame_begin(r.tile, r.d_state, fp, s);
 
-    // queue-driven loop: every launch advances each active pixel by `segments` ray segments and compacts
-    int n_active = n_local;
-    const int* q_in = nullptr;                         // identity queue for the first launch
-    int cur = 0;
+    // queue-driven loop: every launch advances each active pixel by `segments` ray segments and compacts.
+    // The launch reads its exact input count from device memory (the previous launch's output counter), so the host
+    // does not wait for each count: it runs kRunAhead launches ahead, sizing grids with the newest count it HAS seen
+    // (counts only shrink), and stops once a count of 0 has come back; the few launches already queued behind it find
+    // an empty queue and exit.
+    constexpr int kRunAhead = 2, kRing = 4;            // count slots: launch i reads slot (i-1) % kRing, writes i % kRing
+    int bound = n_local;                               // newest count known to the host
     uint64_t launches = 0, visits = 0;
     const size_t first_kernel_event = n_ev;
-    while (n_active > 0) {
-        visits += (uint64_t)n_active;
-        PTMI_HIP(hipMemsetAsync(r.d_count, 0, sizeof(int), s));
-        const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
-        if (stats) PTMI_HIP(hipEventRecord(e0, s));
-        launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, q_in, n_active, r.d_queue[cur], r.d_count, segments,
-                      want_stats ? r.d_stats : nullptr, s);
-        PTMI_HIP(hipGetLastError());                   // launch-time failures (bad LDS size, ...) surface here, not a frame later
-        const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
-        if (stats) PTMI_HIP(hipEventRecord(e1, s));
-        PTMI_HIP(hipMemcpyAsync(r.h_count, r.d_count, sizeof(int), hipMemcpyDeviceToHost, s));
-        PTMI_HIP(hipStreamSynchronize(s));
-        n_active = r.h_count[0];
-        q_in = r.d_queue[cur];
-        cur ^= 1;
-        launches++;
+    hipEvent_t done_ev[kRing];
+    for (int i = 0; i < kRing; i++) done_ev[i] = event(n_ev++);
+    const size_t first_pair_event = n_ev;
+    int issued = 0, retired = 0;
+    bool finished = n_local == 0;
+    while (!finished || retired < issued) {
+        while (!finished && issued - retired < kRunAhead) {
+            const int slot_out = issued % kRing;
+            PTMI_HIP(hipMemsetAsync(r.d_count + slot_out, 0, sizeof(int), s));
+            const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
+            if (stats) PTMI_HIP(hipEventRecord(e0, s));
+            launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, issued == 0 ? nullptr : r.d_queue[(issued - 1) & 1], bound,
+                          issued == 0 ? nullptr : r.d_count + (issued - 1) % kRing, r.d_queue[issued & 1], r.d_count + slot_out,
+                          segments, want_stats ? r.d_stats : nullptr, s);
+            PTMI_HIP(hipGetLastError());               // launch-time failures (bad LDS size, ...) surface here, not a frame later
+            const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
+            if (stats) PTMI_HIP(hipEventRecord(e1, s));
+            PTMI_HIP(hipMemcpyAsync(r.h_count + slot_out, r.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, s));
+            PTMI_HIP(hipEventRecord(done_ev[slot_out], s));
+            issued++;
+        }
+        // retire the oldest outstanding launch: its output count becomes the new bound
+        const int slot = retired % kRing;
+        PTMI_HIP(hipEventSynchronize(done_ev[slot]));
+        const int out_count = r.h_count[slot];
+        if (retired == 0 || last_out > 0) { launches++; visits += (uint64_t)(retired == 0 ? n_local : last_out); }
+        last_out = out_count;
+        bound = out_count;
+        retired++;
+        if (out_count == 0) finished = true;
     }
     launch_resolve(r.tile, r.d_state, g.config.spp, r.d_image, r.d_radiance, s);
     const hipEvent_t ev_end = event(n_ev++);
@@ -355,7 +373,8 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->seconds = ms * 1e-3;
         double kms = 0.0;
-        for (size_t i = first_kernel_event; i + 1 < n_ev - 1; i += 2) {
+        (void)first_kernel_event;
+        for (size_t i = first_pair_event; i + 1 < n_ev - 1; i += 2) {
             float k = 0.0f;
             PTMI_HIP(hipEventElapsedTime(&k, g.event_pool[i], g.event_pool[i + 1]));
             kms += k;
