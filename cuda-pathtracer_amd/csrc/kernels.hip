@@ -6,8 +6,10 @@
 // Kernels
 //   ptmi_render_init   render_init (integrator.h:274-280): XORWOW seeding + 2^67*pixel skip-ahead
 //   ptmi_frame_begin   sample 0's camera ray for every pixel (integrator.h:383-387)
-//   ptmi_bounce        THE hot kernel: intersect (scene.h:50-110, triangle.h:64-96, quad.h:49-132) +
-//                      integrator() body (integrator.h:189-268) + regeneration + queue compaction
+//   ptmi_bounce        THE hot kernel (scenes up to 64 primitives, and deep-tree fallback): intersect (scene.h:50-110,
+//                      triangle.h:64-96, quad.h:49-132) + integrator() body (integrator.h:189-268) + regeneration +
+//                      queue compaction; segment-synchronous, wave-uniform SWEEP walk (or STACK / LANE)
+//   ptmi_bounce_phased the same work for larger scenes: per-lane stackless walk with wave-scheduled NODE/PRIM/SHADE phases
 //   ptmi_resolve       integrator.h:393-407
 #include "device_scene.h"
 

@@ -330,7 +330,6 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     constexpr int kRunAhead = 2, kRing = 4;            // count slots: launch i reads slot (i-1) % kRing, writes i % kRing
     int bound = n_local;                               // newest count known to the host
     uint64_t launches = 0, visits = 0;
-    const size_t first_kernel_event = n_ev;
     hipEvent_t done_ev[kRing];
     for (int i = 0; i < kRing; i++) done_ev[i] = event(n_ev++);
     const size_t first_pair_event = n_ev;
@@ -373,7 +372,6 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->seconds = ms * 1e-3;
         double kms = 0.0;
-        (void)first_kernel_event;
         for (size_t i = first_pair_event; i + 1 < n_ev - 1; i += 2) {
             float k = 0.0f;
             PTMI_HIP(hipEventElapsedTime(&k, g.event_pool[i], g.event_pool[i + 1]));
