@@ -355,7 +355,8 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         const int slot = retired % kRing;
         PTMI_HIP(hipEventSynchronize(done_ev[slot]));
         const int out_count = r.h_count[slot];
-        if (retired == 0 || last_out > 0) { launches++; visits += (uint64_t)(retired == 0 ? n_local : last_out); }
+        launches++;                                    // every issued launch counts (rocprof sees the trailing empty ones too)
+        if (retired == 0 || last_out > 0) visits += (uint64_t)(retired == 0 ? n_local : last_out);
         last_out = out_count;
         bound = out_count;
         retired++;

@@ -88,7 +88,7 @@ typedef struct {
 typedef struct {
     double   seconds;          /* device time of the frame (HIP events around all launches) */
     double   bounce_kernel_ms; /* summed duration of the dominant kernel (ptmi_bounce) */
-    uint64_t bounce_launches;
+    uint64_t bounce_launches;  /* launches issued, incl. the 1-2 queued behind the one that emptied the queue (they exit at once) */
     uint64_t path_visits;      /* sum over launches of queued pixels: each reads + writes its 88-byte state once */
     uint64_t samples;          /* local pixels * spp */
     uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */

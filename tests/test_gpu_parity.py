@@ -243,7 +243,7 @@ def test_result_independent_of_segments_per_launch(R):
         else:
             assert (bits(rad) == bits(ref[1])).all() and (rgb == ref[0]).all(), seg
         if seg == 100000:
-            assert st.bounce_launches == 1        # megakernel limit: one launch does the whole frame
+            assert st.bounce_launches <= 2        # megakernel limit: one launch does the whole frame (+ one run-ahead launch that finds the queue empty)
 
 
 def test_result_independent_of_wave_pixel_layout(R):

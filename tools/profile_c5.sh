@@ -10,3 +10,5 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   rocprofv3 --pmc $PASS --output-format csv -d $OUT/pmc_$NAME -o pmc -- python3 tools/c5_probe.py 1024 64 32 > $OUT/log_$NAME.txt 2>&1 || echo "pass $NAME failed"
   echo pmc-$NAME-done
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 tools/c5_probe.py 1024 64 32 > $OUT/log_trace.txt 2>&1 || echo "trace failed"
+echo trace-done
