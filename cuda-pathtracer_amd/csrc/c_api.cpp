@@ -67,7 +67,7 @@ void ptmi_default_camera(ptmi_camera* c) {
 void ptmi_default_config(ptmi_config* c) {
     const AppConfig d;
     c->spp = d.spp; c->max_depth = d.max_depth; c->sampling_mode = (int)d.sampling_mode; c->seed_base = d.seed_base;
-    c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0;
+    c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0; c->streams = 0;
 }
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
@@ -246,7 +246,9 @@ int ptmi_set_config(ptmi_ctx* c, const ptmi_config* cfg) {
         AppConfig& a = c->app.config;
         a.spp = cfg->spp; a.max_depth = cfg->max_depth; a.sampling_mode = SamplingMode::SAMPLING_BSDF;
         a.seed_base = cfg->seed_base; a.segments_per_launch = cfg->segments_per_launch; a.collect_stats = cfg->collect_stats != 0;
+        need(cfg->streams >= 0 && cfg->streams <= RenderState::kMaxChunks, "streams must be 0..4");
         c->app.render.allow_tile8 = cfg->wave_tiles != 0;
+        c->app.render.want_chunks = cfg->streams;
     });
 }
 

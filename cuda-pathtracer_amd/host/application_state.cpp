@@ -205,12 +205,16 @@ void SceneState::chooseTraversal() {
 // RenderState
 // ------------------------------------------------------------------------------------------------
 void RenderState::freeBuffers() {
-    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance,
-                    d_queue[0], d_queue[1], d_count, d_stats};
+    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h_count) (void)hipHostFree(h_count);
+    for (Chunk& c : chunk) {
+        void* cp[] = {c.d_queue_init, c.d_queue[0], c.d_queue[1], c.d_count};
+        for (void* p : cp) if (p) (void)hipFree(p);
+        if (c.h_count) (void)hipHostFree(c.h_count);
+        c.d_queue_init = c.d_queue[0] = c.d_queue[1] = c.d_count = nullptr; c.h_count = nullptr; c.n = 0;
+    }
     d_state = PathState();
-    d_image = nullptr; d_radiance = nullptr; d_queue[0] = d_queue[1] = nullptr; d_count = nullptr; d_stats = nullptr; h_count = nullptr;
+    d_image = nullptr; d_radiance = nullptr; d_stats = nullptr;
     n_local = 0;
 }
 
@@ -229,11 +233,25 @@ void RenderState::allocateBuffers() {
     d_state.F = (uint2*)hipMallocSafe(n * sizeof(uint2), "state.F");
     d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
     d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
-    d_queue[0] = (int*)hipMallocSafe(n * sizeof(int), "d_queue0");
-    d_queue[1] = (int*)hipMallocSafe(n * sizeof(int), "d_queue1");
-    d_count = (int*)hipMallocSafe(8 * sizeof(int), "d_count");
     d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
-    PTMI_HIP(hipHostMalloc((void**)&h_count, 8 * sizeof(int)));
+    // chunks: 256-slot blocks dealt round-robin, so a workgroup still reads 256 consecutive state records
+    n_chunks = want_chunks > 0 ? std::min(want_chunks, (int)kMaxChunks) : (n_local >= (size_t)(1 << 18) ? 2 : 1);
+    std::vector<std::vector<int>> slots(n_chunks);
+    for (size_t b = 0; b * kBlock < n_local; b++) {
+        std::vector<int>& v = slots[b % n_chunks];
+        for (size_t i = b * kBlock; i < std::min(n_local, (b + 1) * (size_t)kBlock); i++) v.push_back((int)i);
+    }
+    for (int c = 0; c < n_chunks; c++) {
+        Chunk& ch = chunk[c];
+        ch.n = (int)slots[c].size();
+        const size_t cap = std::max<size_t>(slots[c].size(), 1) * sizeof(int);
+        ch.d_queue_init = (int*)hipMallocSafe(cap, "chunk.queue_init");
+        ch.d_queue[0] = (int*)hipMallocSafe(cap, "chunk.queue0");
+        ch.d_queue[1] = (int*)hipMallocSafe(cap, "chunk.queue1");
+        ch.d_count = (int*)hipMallocSafe(kCountRing * sizeof(int), "chunk.count");
+        PTMI_HIP(hipHostMalloc((void**)&ch.h_count, kCountRing * sizeof(int)));
+        if (ch.n) PTMI_HIP(hipMemcpy(ch.d_queue_init, slots[c].data(), slots[c].size() * sizeof(int), hipMemcpyHostToDevice));
+    }
 
     // camera: image size + aspect, then updateCamera (application_state.h:106-109)
     h_camera.image_width = width; h_camera.image_height = height;
@@ -272,6 +290,7 @@ ApplicationState::ApplicationState(int device) : device_id(device) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         throw HipError(hipErrorInvalidDevice, std::string("libptmi is built for gfx950 only; device is ") + prop.gcnArchName);
     PTMI_HIP(hipStreamCreateWithFlags(&render.stream, hipStreamNonBlocking));
+    for (RenderState::Chunk& c : render.chunk) PTMI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     h_jump = buildXorwowJumpMatrices();
     render.d_jump = (uint32_t*)hipMallocSafe(h_jump.size() * sizeof(uint32_t), "d_jump");
     PTMI_HIP(hipMemcpy(render.d_jump, h_jump.data(), h_jump.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -285,6 +304,7 @@ ApplicationState::~ApplicationState() {
     render.freeBuffers();
     if (render.d_jump) (void)hipFree(render.d_jump);
     if (render.stream) (void)hipStreamDestroy(render.stream);
+    for (RenderState::Chunk& c : render.chunk) if (c.stream) (void)hipStreamDestroy(c.stream);
 }
 
 void renderFrame(ApplicationState& g, FrameStats* stats) {
@@ -306,7 +326,6 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
 
     const int n_local = (int)r.n_local;
-    int last_out = 0;                                  // output count of the most recently retired launch
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
     hipStream_t s = r.stream;
     const bool want_stats = g.config.collect_stats;
@@ -322,46 +341,62 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
 
     launch_frame_begin(r.tile, r.d_state, fp, s);
 
-    // queue-driven loop: every launch advances each active pixel by `segments` ray segments and compacts.
-    // The launch reads its exact input count from device memory (the previous launch's output counter), so the host
-    // does not wait for each count: it runs kRunAhead launches ahead, sizing grids with the newest count it HAS seen
-    // (counts only shrink), and stops once a count of 0 has come back; the few launches already queued behind it find
-    // an empty queue and exit.
-    constexpr int kRunAhead = 2, kRing = 4;            // count slots: launch i reads slot (i-1) % kRing, writes i % kRing
-    int bound = n_local;                               // newest count known to the host
-    uint64_t launches = 0, visits = 0;
-    hipEvent_t done_ev[kRing];
-    for (int i = 0; i < kRing; i++) done_ev[i] = event(n_ev++);
-    const size_t first_pair_event = n_ev;
-    int issued = 0, retired = 0;
-    bool finished = n_local == 0;
-    while (!finished || retired < issued) {
-        while (!finished && issued - retired < kRunAhead) {
-            const int slot_out = issued % kRing;
-            PTMI_HIP(hipMemsetAsync(r.d_count + slot_out, 0, sizeof(int), s));
-            const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
-            if (stats) PTMI_HIP(hipEventRecord(e0, s));
-            launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, issued == 0 ? nullptr : r.d_queue[(issued - 1) & 1], bound,
-                          issued == 0 ? nullptr : r.d_count + (issued - 1) % kRing, r.d_queue[issued & 1], r.d_count + slot_out,
-                          segments, want_stats ? r.d_stats : nullptr, s);
-            PTMI_HIP(hipGetLastError());               // launch-time failures (bad LDS size, ...) surface here, not a frame later
-            const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
-            if (stats) PTMI_HIP(hipEventRecord(e1, s));
-            PTMI_HIP(hipMemcpyAsync(r.h_count + slot_out, r.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, s));
-            PTMI_HIP(hipEventRecord(done_ev[slot_out], s));
-            issued++;
-        }
-        // retire the oldest outstanding launch: its output count becomes the new bound
-        const int slot = retired % kRing;
-        PTMI_HIP(hipEventSynchronize(done_ev[slot]));
-        const int out_count = r.h_count[slot];
-        launches++;                                    // every issued launch counts (rocprof sees the trailing empty ones too)
-        if (retired == 0 || last_out > 0) visits += (uint64_t)(retired == 0 ? n_local : last_out);
-        last_out = out_count;
-        bound = out_count;
-        retired++;
-        if (out_count == 0) finished = true;
+    // queue-driven loop: every launch advances each active pixel of its chunk by `segments` ray segments and compacts.
+    // A launch reads its exact input count from device memory (the previous launch's output counter), so the host
+    // does not wait for each count: per chunk it runs kRunAhead launches ahead, sizing grids with the newest count it
+    // HAS seen (counts only shrink), and stops once a count of 0 has come back; the launches already queued behind it
+    // find an empty queue and exit.  The chunks' streams run concurrently.
+    constexpr int kRunAhead = 2, kRing = RenderState::kCountRing;   // count slots: launch i reads (i-1) % kRing, writes i % kRing
+    struct Run { int bound, last_out = 0, issued = 0, retired = 0; bool finished; hipEvent_t done[kRing]; };
+    Run run[RenderState::kMaxChunks];
+    const hipEvent_t ev_ready = event(n_ev++);
+    PTMI_HIP(hipEventRecord(ev_ready, s));             // frame_begin (and the stats reset) precede every chunk's first launch
+    for (int c = 0; c < r.n_chunks; c++) {
+        run[c].bound = r.chunk[c].n; run[c].finished = r.chunk[c].n == 0;
+        for (int i = 0; i < kRing; i++) run[c].done[i] = event(n_ev++);
+        PTMI_HIP(hipStreamWaitEvent(r.chunk[c].stream, ev_ready, 0));
     }
+    uint64_t launches = 0, visits = 0;
+    const size_t first_pair_event = n_ev;
+    auto busy = [&] { for (int c = 0; c < r.n_chunks; c++) if (!run[c].finished || run[c].retired < run[c].issued) return true; return false; };
+    while (busy()) {
+        for (int c = 0; c < r.n_chunks; c++) {
+            Run& u = run[c]; RenderState::Chunk& ch = r.chunk[c];
+            while (!u.finished && u.issued - u.retired < kRunAhead) {
+                const int slot_out = u.issued % kRing;
+                PTMI_HIP(hipMemsetAsync(ch.d_count + slot_out, 0, sizeof(int), ch.stream));
+                const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
+                if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
+                launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
+                              u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
+                              segments, want_stats ? r.d_stats : nullptr, ch.stream);
+                PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
+                const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
+                if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
+                PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
+                PTMI_HIP(hipEventRecord(u.done[slot_out], ch.stream));
+                u.issued++;
+            }
+        }
+        for (int c = 0; c < r.n_chunks; c++) {         // retire each chunk's oldest outstanding launch: its count is the new bound
+            Run& u = run[c]; RenderState::Chunk& ch = r.chunk[c];
+            if (u.retired == u.issued) continue;
+            const int slot = u.retired % kRing;
+            PTMI_HIP(hipEventSynchronize(u.done[slot]));
+            const int out_count = ch.h_count[slot];
+            launches++;                                // every issued launch counts (rocprof sees the trailing empty ones too)
+            if (u.retired == 0 || u.last_out > 0) visits += (uint64_t)(u.retired == 0 ? ch.n : u.last_out);
+            u.last_out = out_count; u.bound = out_count;
+            u.retired++;
+            if (out_count == 0) u.finished = true;
+        }
+    }
+    for (int c = 0; c < r.n_chunks; c++) {             // the resolve pass waits for every chunk
+        const hipEvent_t ev = event(n_ev++);
+        PTMI_HIP(hipEventRecord(ev, r.chunk[c].stream));
+        PTMI_HIP(hipStreamWaitEvent(s, ev, 0));
+    }
+    const size_t after_pairs = n_ev;
     launch_resolve(r.tile, r.d_state, g.config.spp, r.d_image, r.d_radiance, s);
     const hipEvent_t ev_end = event(n_ev++);
     PTMI_HIP(hipEventRecord(ev_end, s));
@@ -373,7 +408,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->seconds = ms * 1e-3;
         double kms = 0.0;
-        for (size_t i = first_pair_event; i + 1 < n_ev - 1; i += 2) {
+        for (size_t i = first_pair_event; i + 1 < after_pairs - (size_t)r.n_chunks; i += 2) {
             float k = 0.0f;
             PTMI_HIP(hipEventElapsedTime(&k, g.event_pool[i], g.event_pool[i + 1]));
             kms += k;

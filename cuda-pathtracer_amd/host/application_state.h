@@ -81,8 +81,18 @@ struct RenderState {
     PathState d_state;                               // path state + RNG (replaces d_rand_state)
     unsigned char* d_image = nullptr;                // RGB8, local rows
     float* d_radiance = nullptr;                     // float3 mean radiance, local rows
-    int *d_queue[2] = {nullptr, nullptr}, *d_count = nullptr;
-    int* h_count = nullptr;                          // pinned
+    // The local pixels are dealt to kMaxChunks independent queues (256-slot blocks, round-robin), each driven through
+    // its own stream: while one chunk's launch drains (kernel tail, state write-back burst) the other chunk's
+    // workgroups keep the CUs busy.  Chunks share nothing but the read-only scene.
+    static constexpr int kMaxChunks = 4, kCountRing = 4;
+    struct Chunk {
+        hipStream_t stream = nullptr;
+        int n = 0;                                   // pixels in this chunk
+        int *d_queue_init = nullptr, *d_queue[2] = {nullptr, nullptr}, *d_count = nullptr;
+        int* h_count = nullptr;                      // pinned, kCountRing entries
+    } chunk[kMaxChunks];
+    int n_chunks = 1;
+    int want_chunks = 0;                             // 0 = automatic, else forced (scheduling knob)
     StatCounters* d_stats = nullptr;
     uint32_t* d_jump = nullptr;                      // XORWOW skip-ahead matrices (owned by the ctx, set before allocateBuffers)
     uint64_t seed_base = 2023;

@@ -34,7 +34,7 @@ class Camera(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("spp", C.c_int), ("max_depth", C.c_int), ("sampling_mode", C.c_int), ("seed_base", C.c_uint64),
-                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int)]
+                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int)]
 
 
 class Tiling(C.Structure):
@@ -246,7 +246,7 @@ class Renderer:
     def set_camera(self, cam):
         self._ck(self.L.ptmi_set_camera(self.h, C.byref(cam)))
 
-    def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None, wave_tiles=None):
+    def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None, wave_tiles=None, streams=None):
         c = self.config
         if spp is not None: c.spp = int(spp)
         if max_depth is not None: c.max_depth = int(max_depth)
@@ -254,6 +254,7 @@ class Renderer:
         if segments_per_launch is not None: c.segments_per_launch = int(segments_per_launch)
         if collect_stats is not None: c.collect_stats = int(bool(collect_stats))
         if wave_tiles is not None: c.wave_tiles = int(bool(wave_tiles))
+        if streams is not None: c.streams = int(streams)
         self._ck(self.L.ptmi_set_config(self.h, C.byref(c)))
 
     def camera_frame(self):

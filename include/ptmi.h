@@ -72,6 +72,10 @@ typedef struct {
      * 1 = 8x8 pixel tiles (when width and this rank's row count are multiples of 8; measured -1 % with the sweep walk,
      * +1 % with the per-lane walk).  Takes effect at the next ptmi_update_resolution. */
     int      wave_tiles;
+    /* scheduling knob, results are independent of it: number of independent pixel chunks, each driven through its own
+     * HIP stream so that one chunk's kernel tail overlaps the other's body.  0 = default (2 for frames of >= 2^18 local
+     * pixels, else 1), 1 = single stream.  Takes effect at the next ptmi_update_resolution. */
+    int      streams;
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).

@@ -261,6 +261,23 @@ def test_result_independent_of_wave_pixel_layout(R):
     R.set_config(wave_tiles=0)
 
 
+def test_result_independent_of_stream_chunks(R):
+    """One stream vs two independent pixel chunks on two streams: scheduling only."""
+    R.load_scene(os.path.join(SCENES, "cbox.obj"))
+    out = []
+    for streams in (1, 2):
+        R.set_config(spp=5, max_depth=5, streams=streams, segments_per_launch=3, collect_stats=True)
+        R.update_resolution(200, 120)
+        st = R.render_frame()
+        out.append(R.read_image() + (st,))
+    assert (bits(out[0][1]) == bits(out[1][1])).all() and (out[0][0] == out[1][0]).all()
+    assert (out[0][2].rays, out[0][2].node_visits, out[0][2].prim_tests) == (out[1][2].rays, out[1][2].node_visits, out[1][2].prim_tests)
+    assert out[0][2].path_visits == out[1][2].path_visits
+    orgb, orad, _ = OracleScene.load(os.path.join(SCENES, "cbox.obj")).render(default_camera(), 200, 120, 5)
+    assert_same_image(out[1][0], out[1][1], orgb, orad, "2 streams")
+    R.set_config(streams=0, segments_per_launch=0, collect_stats=False)
+
+
 def test_rng_state_persists_across_frames(R):
     """No accumulation across frames, only the RNG carries over (integrator.h:379)."""
     W = H = 48
