@@ -93,6 +93,8 @@ def main():
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: ranks share devices and the gather
     # goes through host memory with gloo.  Never used for reported numbers.
     ap.add_argument("--rehearse-gloo", action="store_true", help=argparse.SUPPRESS)
+    # exercise the RCCL code path (init, gather, barrier) even with one rank; never used for reported numbers
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +111,8 @@ def main():
     device_index = local_rank % torch.cuda.device_count() if args.rehearse_gloo else local_rank
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_gloo:
@@ -138,7 +141,7 @@ def main():
 
     def step(stats):
         st = r.render_frame(want_stats=stats)
-        if world > 1:
+        if use_dist:
             if args.rehearse_gloo:
                 rgb, rad = r.read_image()
                 fg.send_rgb[:n_local_rows] = torch.from_numpy(rgb); fg.send_rad[:n_local_rows] = torch.from_numpy(rad)
@@ -150,7 +153,7 @@ def main():
         return st
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +179,7 @@ def main():
         kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; visits += st.path_visits; frame_dev_s += st.seconds
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -228,7 +231,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(side)
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

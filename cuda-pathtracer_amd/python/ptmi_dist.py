@@ -37,7 +37,7 @@ class FrameGather:
 
     def gather(self):
         """send_rad / send_rgb[:n_local] must hold this rank's rows.  Returns (frame_rad, frame_rgb) on dst, else None."""
-        if self.world == 1:
+        if self.world == 1 and self.dist is None:
             return self.send_rad[: self.n_local], self.send_rgb[: self.n_local]
         is_dst = self.rank == self.dst
         self.dist.gather(self.send, self.recv if is_dst else None, dst=self.dst)
