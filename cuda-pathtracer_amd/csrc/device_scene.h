@@ -43,7 +43,12 @@ struct DeviceScene {
     int stack_entries = 1;    // min(bvh depth + 1, 64); only the STACK traversal uses it
     int lds_resident = 0;     // 1: nodes+prims+mats are staged into LDS by every workgroup (LANE/STACK traversal)
     int traversal = 1;        // TraversalMode
+    // Guided sampling (SamplingMode != BSDF): one PrecomputedCDF record per primitive in LOAD order
+    // (render_config.h:24-31: pdf[256], row_sums[8], marginal_cdf[8], row_cdfs[256], total_weight, is_valid = 530
+    // dwords = 2120 B), HBM/L2-resident, read per hit through the load-order index kept in mats[3k].w.  nullptr = none.
+    const float* cdfs = nullptr;
 };
+constexpr int kCdfDwords = 530, kCdfPdf = 0, kCdfRowSums = 256, kCdfMarginal = 264, kCdfRowCdfs = 272, kCdfTotal = 528, kCdfValid = 529;
 
 // How ptmi_bounce walks the BVH.  All three visit the same nodes and primitives in the same order per ray.
 enum TraversalMode {
@@ -70,6 +75,8 @@ struct TileMap {              // local row -> global row (ptmi.h: ptmi_tiling)
 struct FrameParams {
     float cam_origin[3], cam_llc[3], cam_hor[3], cam_ver[3];
     int spp, max_depth;
+    int sampling_mode;          // SamplingMode (render_config.h:38-44)
+    float mis_bsdf_fraction;    // Scene::mis_bsdf_fraction (scene.h:217)
 };
 
 struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits; };

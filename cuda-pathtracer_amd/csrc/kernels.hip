@@ -456,11 +456,106 @@ __device__ __forceinline__ void store_path(const PathState& st, int slot, const 
     st.F[slot] = make_uint2(p.rng.v4, p.rng.d);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Guided sampling: Grid over a PrecomputedCDF record (rendering/grid.h), MIS (integrator.h:91-167)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_frame(f3 n, f3& t, f3& b) {                 // grid.h:287-297
+    if (n.z < -0.9999999f) { t = mk3(0.0f, -1.0f, 0.0f); b = mk3(-1.0f, 0.0f, 0.0f); return; }
+    const float a = rcp_rn(1.0f + n.z);
+    const float c = -n.x * n.y * a;
+    t = mk3(1.0f - n.x * n.x * a, c, -n.x);
+    b = mk3(c, 1.0f - n.y * n.y * a, -n.y);
+}
+__device__ __forceinline__ int linear_search_cdf(const float* __restrict__ cdf, int size, float xi) {   // grid.h:233-240
+    xi = fminf(fmaxf(xi, 0.0f), 0.999999f);
+    int r = size - 1;
+    for (int i = size - 1; i >= 0; i--) if (xi < cdf[i]) r = i;      // first i with xi < cdf[i]
+    return r;
+}
+__device__ __forceinline__ float grid_pdf_for_cell(const float* __restrict__ g, int theta_idx, int phi_idx) {   // grid.h:242-253
+    const float cell_value = g[kCdfPdf + theta_idx * 16 + phi_idx];
+    if (cell_value < 1e-8f) return 1e-6f;
+    const float cell_prob = cell_value / fmaxf(g[kCdfTotal], 1e-6f);
+    const float theta_center = (float)((double)(((float)theta_idx + 0.5f) * 0.125f) * (PTMI_PI_D * 0.5f));
+    float st, ct;
+    ptmi_sincosf(theta_center, &st, &ct);
+    const float sin_theta = fmaxf(st, 0.01f);
+    const float solid_angle = (float)(((double)sin_theta * ((PTMI_PI_D * 0.5f) / 8)) * (2.0f * PTMI_PI_D / 16));
+    return cell_prob / fmaxf(solid_angle, 1e-6f);
+}
+__device__ __forceinline__ f3 grid_sample(const float* __restrict__ g, f3 normal, Rng& rng, float& out_pdf) {   // grid.h:141-188
+    const float xi1 = rng_uniform(rng);
+    const float xi2 = rng_uniform(rng);
+    const int theta_idx = linear_search_cdf(g + kCdfMarginal, 8, xi1);
+    const int phi_idx = linear_search_cdf(g + kCdfRowCdfs + theta_idx * 16, 16, xi2);
+    const float jitter_theta = rng_uniform(rng);
+    const float jitter_phi = rng_uniform(rng);
+    float theta = (float)((double)(((float)theta_idx + jitter_theta) * 0.125f) * (PTMI_PI_D * 0.5f));
+    theta = fminf(theta, (float)(PTMI_PI_D * 0.5f - (double)0.01f));
+    const float phi = (float)((double)((((float)phi_idx + jitter_phi) * 0.0625f) * 2.0f) * PTMI_PI_D);
+    float sin_t, cos_t, sin_p, cos_p;
+    ptmi_sincosf(theta, &sin_t, &cos_t);
+    ptmi_sincosf(phi, &sin_p, &cos_p);
+    f3 tangent, bitangent;
+    build_frame(normal, tangent, bitangent);
+    const f3 world = unit_vector((sin_t * cos_p) * tangent + (sin_t * sin_p) * bitangent + cos_t * normal);
+    out_pdf = grid_pdf_for_cell(g, theta_idx, phi_idx);
+    return world;
+}
+__device__ __forceinline__ float grid_compute_pdf(const float* __restrict__ g, f3 dir, f3 normal) {   // grid.h:200-216, 299-310
+    f3 tangent, bitangent;
+    build_frame(normal, tangent, bitangent);
+    const float lx = dot(dir, tangent), ly = dot(dir, bitangent), lz = dot(dir, normal);
+    const float theta = ptmi_acosf(fminf(fmaxf(lz, -1.0f), 1.0f));
+    float phi = ptmi_atan2f(ly, lx);
+    if (phi < 0.0f) phi = (float)((double)phi + (double)2.0f * PTMI_PI_D);
+    if ((double)theta > PTMI_PI_D * 0.5f) return 0.0f;
+    int theta_idx = (int)(((double)theta * ((double)2.0f / PTMI_PI_D)) * 8);
+    int phi_idx = (int)(((double)phi * ((double)0.5f / PTMI_PI_D)) * 16);
+    theta_idx = max(0, min(theta_idx, 7));
+    phi_idx = max(0, min(phi_idx, 15));
+    return grid_pdf_for_cell(g, theta_idx, phi_idx);
+}
+__device__ __forceinline__ float mis_power_heuristic(float pdf_a, float pdf_b) {   // integrator.h:91-96
+    if (pdf_a <= 0.0f) return 0.0f;
+    const float a2 = pdf_a * pdf_a, b2 = pdf_b * pdf_b;
+    return a2 / (a2 + b2);
+}
+__device__ __forceinline__ f3 cosine_hemisphere(f3 n, float u, float v);
+__device__ __forceinline__ f3 sample_mis(const float* __restrict__ g, f3 normal, Rng& rng, float& weight, float bsdf_prob) {   // integrator.h:112-167
+    const float BSDF_PROB = fmaxf(fminf(bsdf_prob, 0.99f), 0.01f);
+    const float GRID_PROB = 1.0f - BSDF_PROB;
+    const float xi = rng_uniform(rng);
+    f3 dir;
+    if (xi < BSDF_PROB) {
+        const float u = rng_uniform(rng), v = rng_uniform(rng);
+        dir = cosine_hemisphere(normal, u, v);
+        const float cos_theta = fmaxf(dot(dir, normal), 0.0f);
+        const float pdf_bsdf = (float)((double)cos_theta / PTMI_PI_D);
+        const float pdf_grid = grid_compute_pdf(g, dir, normal);
+        const float mis_w = mis_power_heuristic(pdf_bsdf, pdf_grid);
+        weight = (pdf_bsdf > 1e-6f) ? mis_w / BSDF_PROB : 0.0f;
+    } else {
+        float pdf_grid;
+        dir = grid_sample(g, normal, rng, pdf_grid);
+        const float cos_theta = fmaxf(dot(dir, normal), 0.0f);
+        const float pdf_bsdf = (float)((double)cos_theta / PTMI_PI_D);
+        const float mis_w = mis_power_heuristic(pdf_grid, pdf_bsdf);
+        if (pdf_grid > 1e-6f && cos_theta > 0.0f) {
+            const float w = (float)((double)(mis_w * cos_theta) / ((PTMI_PI_D * (double)pdf_grid) * (double)GRID_PROB));
+            weight = fminf(w, 10.0f);
+        } else weight = 0.0f;
+    }
+    return dir;
+}
+
 // One iteration of integrator()'s depth loop after the intersection (integrator.h:198-266), plus the end of the
 // sample and the head of the next spp iteration (integrator.h:383-390) when the path ends.
 // Returns true while the pixel still has a ray to trace; false once all spp samples are done.
-template <bool STATS>
-__device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const float4* mats, PathRegs& p,
+// GUIDED: the grid / MIS branches of integrator.h:232-263 are compiled in (sampling_mode != SAMPLING_BSDF with CDF
+// records present); the plain BSDF instantiation carries none of that code.
+template <bool STATS, bool GUIDED>
+__device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const float4* mats, const float* cdfs, PathRegs& p,
                                            bool hit, float t, int k, LaneCounters& cn) {
     bool end_sample = !hit;                                                       // integrator.h:198-201
     if (hit) {
@@ -479,14 +574,40 @@ __device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap&
             if (length(p.tp) < 1e-5f) end_sample = true;                          // integrator.h:218
             else {
                 const f3 sn = dot(p.d, n) < 0 ? n : -n;                           // integrator.h:221-222
-                const float u = rng_uniform(p.rng);                               // integrator.h:63-64
-                const float v = rng_uniform(p.rng);
-                p.depth++;
-                if (p.depth < fp.max_depth) {
-                    const f3 next = cosine_hemisphere(sn, u, v);                  // integrator.h:230
-                    p.o = hp + 1e-4f * sn;                                        // integrator.h:266
-                    p.d = unit_vector(next);                                      // Ray ctor normalises again
-                } else end_sample = true;                                         // loop bound; the draws above are still consumed
+                // initGridFromPrimitive (integrator.h:31-57): the primitive's precomputed record, if it is valid
+                const float* g = nullptr;
+                if (GUIDED) {
+                    const float* rec = cdfs + (size_t)__float_as_int(mats[3 * k].w) * kCdfDwords;
+                    if (__float_as_int(rec[kCdfValid]) != 0) g = rec;
+                }
+                if (GUIDED && g) {
+                    f3 next;
+                    float weight = 1.0f;
+                    if (fp.sampling_mode == 3) {                                  // SAMPLING_MIS, integrator.h:238-241
+                        next = sample_mis(g, sn, p.rng, weight, fp.mis_bsdf_fraction);
+                    } else {                                                      // pure grid sampling, integrator.h:242-257
+                        float grid_pdf;
+                        next = grid_sample(g, sn, p.rng, grid_pdf);
+                        const float cos_theta = fmaxf(dot(next, sn), 0.0f);
+                        weight = (float)((double)cos_theta / (PTMI_PI_D * (double)fmaxf(grid_pdf, 1e-6f)));
+                        weight = fminf(fmaxf(weight, 0.0f), 10.0f);
+                    }
+                    p.tp = mk3(p.tp.x * weight, p.tp.y * weight, p.tp.z * weight);
+                    p.depth++;
+                    if (p.depth < fp.max_depth) {
+                        p.o = hp + 1e-4f * sn;                                    // integrator.h:266
+                        p.d = unit_vector(next);
+                    } else end_sample = true;
+                } else {                                                          // BSDF mode, or the cosine fallback :258-261
+                    const float u = rng_uniform(p.rng);                           // integrator.h:63-64
+                    const float v = rng_uniform(p.rng);
+                    p.depth++;
+                    if (p.depth < fp.max_depth) {
+                        const f3 next = cosine_hemisphere(sn, u, v);              // integrator.h:230
+                        p.o = hp + 1e-4f * sn;                                    // integrator.h:266
+                        p.d = unit_vector(next);                                  // Ray ctor normalises again
+                    } else end_sample = true;                                     // loop bound; the draws above are still consumed
+                }
             }
         }
     }
@@ -545,7 +666,7 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
 // for SWEEP), then the traversal stacks (STACK only).
 // amdgpu_num_sgpr(80): with <= 80 SGPRs eight 256-thread workgroups fit a CU instead of six
 // (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
-template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS>
+template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
@@ -570,7 +691,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
         if (STATS && alive) cn.rays++;
         const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
                                                                p.o, p.d, 1e-4f, FLT_MAX, t, k, cn);
-        if (alive) alive = shade_step<STATS>(a.fp, a.tm, mats, p, hit, t, k, cn);
+        if (alive) alive = shade_step<STATS, GUIDED>(a.fp, a.tm, mats, a.sc.cdfs, p, hit, t, k, cn);
     }
 
     if (active) store_path(a.st, slot, p);
@@ -587,7 +708,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
 #ifndef PTMI_NODE_BURST
 #define PTMI_NODE_BURST 3
 #endif
-template <bool LDS_GEOM, bool HAS_QUADS, bool STATS>
+template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
     extern __shared__ float4 smem[];
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -645,7 +766,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
             }
         } else {
             if (phase == PH_SHADE) {
-                const bool more = shade_step<STATS>(a.fp, a.tm, mats, p, slot_hit >= 0, closest_t, slot_hit, cn);
+                const bool more = shade_step<STATS, GUIDED>(a.fp, a.tm, mats, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn);
                 segs_left--;
                 if (!more) { alive = false; phase = PH_DONE; }
                 else if (segs_left == 0) phase = PH_DONE;              // state goes back to HBM with the next ray ready
@@ -671,9 +792,13 @@ size_t bounce_lds_bytes(const DeviceScene& sc) {
     return b;
 }
 
+// guided = sampling_mode != SAMPLING_BSDF and CDF records present; otherwise the lean BSDF instantiation runs
+static bool is_guided(const BounceArgs& a) { return a.fp.sampling_mode != 0 && a.sc.cdfs != nullptr; }
+
 template <int MODE, bool G_, bool Q_, bool S_>
 static void launch_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_>), grid, dim3(kBlock), lds, s, a);
+    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true>), grid, dim3(kBlock), lds, s, a);
+    else hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false>), grid, dim3(kBlock), lds, s, a);
 }
 template <int MODE, bool G_>
 static void launch_qs(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -690,15 +815,19 @@ static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipSt
     if (MODE == TRAVERSAL_SWEEP || a.sc.lds_resident) launch_qs<MODE, true>(a, grid, lds, s);
     else if (MODE != TRAVERSAL_SWEEP) launch_qs<MODE == TRAVERSAL_SWEEP ? TRAVERSAL_STACK : MODE, false>(a, grid, lds, s);
 }
+template <bool G_, bool Q_, bool S_>
+static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true>), grid, dim3(kBlock), lds, s, a);
+    else hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false>), grid, dim3(kBlock), lds, s, a);
+}
 template <bool G_>
 static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    const dim3 block(kBlock);
     switch (key) {
-        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<G_, false, false>), grid, block, lds, s, a); break;
-        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<G_, false, true>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<G_, true, false>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((ptmi_bounce_phased<G_, true, true>), grid, block, lds, s, a); break;
+        case 0: launch_phased_one<G_, false, false>(a, grid, lds, s); break;
+        case 1: launch_phased_one<G_, false, true>(a, grid, lds, s); break;
+        case 2: launch_phased_one<G_, true, false>(a, grid, lds, s); break;
+        default: launch_phased_one<G_, true, true>(a, grid, lds, s); break;
     }
 }
 

@@ -82,7 +82,9 @@ void SceneState::cleanup() {
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_prims) (void)hipFree(d_prims);
     if (d_mats) (void)hipFree(d_mats);
-    d_nodes = d_prims = d_mats = nullptr;
+    if (d_precomputed_cdfs) (void)hipFree(d_precomputed_cdfs);
+    d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr;
+    h_precomputed_cdfs.clear();
     d_scene = DeviceScene();
     h_primitives.clear(); bvh_nodes.clear(); bvh_indices.clear();
     num_tris = num_quads = 0; bvh_depth = 0;
@@ -188,6 +190,52 @@ void SceneState::upload() {
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
     chooseTraversal();
+}
+
+void SceneState::precomputeCDFs(const float* rgb) {
+    if (!d_nodes) throw ArgError("precomputeCDFs: no scene loaded");
+    if (d_precomputed_cdfs) { (void)hipFree(d_precomputed_cdfs); d_precomputed_cdfs = nullptr; }
+    h_precomputed_cdfs.clear();
+    d_scene.cdfs = nullptr;
+    if (!rgb) return;
+    const int n = (int)h_primitives.size();
+    constexpr int GRID_RES = 16, GRID_SIZE = 256, GRID_HALF_RES = 8;
+    const float GRID_INV_RES = 1.0f / GRID_RES;
+    h_precomputed_cdfs.assign((size_t)n * kCdfDwords, 0.0f);
+    for (int p = 0; p < n; p++) {
+        float* cdf = &h_precomputed_cdfs[(size_t)p * kCdfDwords];
+        float* pdf = cdf + kCdfPdf; float* row_sums = cdf + kCdfRowSums; float* marginal = cdf + kCdfMarginal; float* row_cdfs = cdf + kCdfRowCdfs;
+        const float* g = rgb + (size_t)p * GRID_SIZE * 3;
+        for (int i = 0; i < GRID_SIZE; i++) pdf[i] = 0.2126f * g[3 * i] + 0.7152f * g[3 * i + 1] + 0.0722f * g[3 * i + 2];   // luminance
+        float total_weight = 0.0f;
+        for (int v = 0; v < GRID_HALF_RES; v++) {                       // upper hemisphere rows only
+            float row_sum = 0.0f;
+            for (int u = 0; u < GRID_RES; u++) row_sum += pdf[v * GRID_RES + u];
+            row_sums[v] = row_sum;
+            total_weight += row_sum;
+        }
+        float running = 0.0f;
+        const float inv_total = (total_weight > 1e-6f) ? (1.0f / total_weight) : 0.0f;
+        for (int v = 0; v < GRID_HALF_RES; v++) { running += row_sums[v]; marginal[v] = running * inv_total; }
+        marginal[GRID_HALF_RES - 1] = 1.0f;
+        for (int v = 0; v < GRID_RES; v++) {
+            const int ro = v * GRID_RES;
+            if (v >= GRID_HALF_RES || row_sums[v] < 1e-6f) {            // empty or lower-hemisphere row: uniform CDF
+                for (int u = 0; u < GRID_RES; u++) row_cdfs[ro + u] = (u + 1) * GRID_INV_RES;
+            } else {
+                float running_row = 0.0f;
+                const float inv_row_sum = 1.0f / row_sums[v];
+                for (int u = 0; u < GRID_RES; u++) { running_row += pdf[ro + u]; row_cdfs[ro + u] = running_row * inv_row_sum; }
+                row_cdfs[ro + GRID_RES - 1] = 1.0f;
+            }
+        }
+        cdf[kCdfTotal] = total_weight;
+        const int valid = total_weight > 1e-6f ? 1 : 0;
+        std::memcpy(&cdf[kCdfValid], &valid, sizeof valid);
+    }
+    d_precomputed_cdfs = (float*)hipMallocSafe(h_precomputed_cdfs.size() * sizeof(float), "d_precomputed_cdfs");
+    PTMI_HIP(hipMemcpy(d_precomputed_cdfs, h_precomputed_cdfs.data(), h_precomputed_cdfs.size() * sizeof(float), hipMemcpyHostToDevice));
+    d_scene.cdfs = d_precomputed_cdfs;
 }
 
 // traversal choice (results are identical in all three; see device_scene.h)
@@ -311,7 +359,6 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     RenderState& r = g.render;
     if (!g.scene.d_nodes) throw ArgError("renderFrame: no scene loaded");
     if (!r.d_state.A) throw ArgError("renderFrame: buffers not allocated (call updateResolution first)");
-    if (g.config.sampling_mode != SamplingMode::SAMPLING_BSDF) throw ArgError("only SAMPLING_BSDF is implemented");
     if (g.config.spp < 1 || g.config.spp >= (1 << 24)) throw ArgError("spp must be in [1, 2^24)");
     if (g.config.max_depth < 1 || g.config.max_depth > 255) throw ArgError("max_depth must be in [1, 255]");
     PTMI_HIP(hipSetDevice(g.device_id));
@@ -324,6 +371,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     float* dst[4] = {fp.cam_origin, fp.cam_llc, fp.cam_hor, fp.cam_ver};
     for (int i = 0; i < 4; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
     fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
+    fp.sampling_mode = (int)g.config.sampling_mode; fp.mis_bsdf_fraction = g.config.mis_bsdf_fraction;
 
     const int n_local = (int)r.n_local;
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;

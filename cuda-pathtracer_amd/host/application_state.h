@@ -44,6 +44,7 @@ struct AppConfig {                                   // application_state.h:262-
     bool orbit = true;                               // renderFrame() always calls updateCameraOrbit()
     int segments_per_launch = 0;                     // 0 = default
     bool collect_stats = false;
+    float mis_bsdf_fraction = 0.5f;                  // application_state.h:292 / scene.h:217
 };
 
 struct SceneState {
@@ -56,6 +57,13 @@ struct SceneState {
 
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_mats = nullptr;
     DeviceScene d_scene;
+    // guided sampling: per-primitive PrecomputedCDF records (render_config.h:24-31), load order
+    std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords
+    float* d_precomputed_cdfs = nullptr;
+    // precomputeCDFs — application_state.h:492-585, from per-primitive 16x16 radiosity grids (n_prims*256*3 floats, load
+    // order; nullptr drops the records).  The radiosity solver that fills the grids in the reference is out of scope:
+    // the grids are an input.
+    void precomputeCDFs(const float* radiosity_grids_rgb);
     int sweep_max_prims = 64;                        // scenes up to this many primitives use the wave-uniform sweep
     int force_traversal = -1;                        // test/benchmark override (TraversalMode), -1 = automatic
 

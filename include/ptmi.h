@@ -61,7 +61,10 @@ typedef struct {
 typedef struct {
     int      spp;             /* AppConfig::spp, default 1 (UI range 1-1000, ui_windows.h:84) */
     int      max_depth;       /* 5 = reference behaviour */
-    int      sampling_mode;   /* SamplingMode (render_config.h:38-44); only 0 = SAMPLING_BSDF is built */
+    int      sampling_mode;   /* SamplingMode (render_config.h:38-44): 0 BSDF, 1 FORMFACTOR, 2 RADIOSITY, 4 TOPK (all three: pure
+                               * grid sampling, integrator.h:242-257), 3 MIS (integrator.h:238-241).  Modes 1-4 need the records
+                               * of ptmi_set_radiosity_grids; without them they fall back to cosine sampling exactly as the
+                               * reference does for primitives with an empty grid (integrator.h:258-261) */
     uint64_t seed_base;       /* 2023 */
     /* scheduling knob, results are independent of it: ray segments each path
      * advances per kernel launch before state returns to HBM and the active
@@ -76,6 +79,7 @@ typedef struct {
      * HIP stream so that one chunk's kernel tail overlaps the other's body.  0 = default (2 for frames of >= 2^18 local
      * pixels, else 1), 1 = single stream.  Takes effect at the next ptmi_update_resolution. */
     int      streams;
+    float    mis_bsdf_fraction;   /* AppConfig::mis_bsdf_fraction, 0.5 (application_state.h:292) */
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).
@@ -121,6 +125,15 @@ int ptmi_scene_info(const ptmi_ctx*, int* n_prims, int* n_tris, int* n_quads, in
 /* Host copies for inspection/tests; arrays sized from ptmi_scene_info. Any pointer may be NULL. */
 int ptmi_scene_get_prims(const ptmi_ctx*, int* type, float* verts, float* normal, float* bsdf, float* Le);
 int ptmi_scene_get_bvh(const ptmi_ctx*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
+
+/* ---- SceneState::precomputeCDFs (application_state.h:492-585) -----------------------------------------------------
+ * Per-primitive 16x16 directional radiosity grids -> the 2120-byte PrecomputedCDF records the guided sampling modes
+ * read (render_config.h:24-31).  rgb: n_prims * 256 * 3 floats in load order (n_prims must match the loaded scene);
+ * NULL drops the records.  In the reference the grids come out of the radiosity pre-pass (form_factors.h), which is
+ * out of scope here: they are an input.  Loading another scene drops the records. */
+int ptmi_set_radiosity_grids(ptmi_ctx*, int n_prims, const float* rgb);
+/* host copy of the records, n_prims * 530 dwords (is_valid as an int bit pattern); returns PTMI_E_INVALID if there are none */
+int ptmi_get_precomputed_cdfs(const ptmi_ctx*, float* out);
 
 /* ---- RenderState::allocateBuffers / updateResolution (application_state.h:91-129)
  * (Re)allocates the image, path-state and RNG buffers for this rank's rows of a

@@ -149,4 +149,48 @@ PTMI_HD float ptmi_powf(float x, float y) {
     return (float)ptmi_exp_d((double)y * l);
 }
 
+/* ---- atan / atan2 / acos in binary64 (grid.h:307-308 worldToSpherical uses acosf / atan2f) ------------------
+ * fdlibm s_atan.c reduction and minimax polynomial (error < 1 ulp of binary64), IEEE binary64 sqrt for acos;
+ * as everywhere in this file: no fma, results rounded once to binary32 by the float wrappers. */
+PTMI_HD double ptmi_atan_d(double x) {
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    const int neg = x < 0.0;
+    double ax = neg ? -x : x;
+    double hi = 0.0, lo = 0.0;
+    int id = -1;
+    if (ax >= 0.4375) {
+        if (ax < 0.6875)      { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+        else if (ax < 1.1875) { id = 1; ax = (ax - 1.0) / (ax + 1.0);       hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+        else if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+        else                  { id = 3; ax = -1.0 / ax;                     hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    }
+    const double z = ax * ax, w = z * z;
+    const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    double r;
+    if (id < 0) r = ax - ax * (s1 + s2);
+    else r = hi - ((ax * (s1 + s2) - lo) - ax);
+    return neg ? -r : r;
+}
+PTMI_HD double ptmi_atan2_d(double y, double x) {
+    const double PI = 3.14159265358979311600e+00, PI_LO = 1.2246467991473531772e-16;
+    if (x != x || y != y) return x + y;
+    if (y == 0.0) return (x > 0.0 || (x == 0.0 && !(ptmi_d2u(x) >> 63))) ? y : ((ptmi_d2u(y) >> 63) ? -PI : PI);
+    if (x == 0.0) return y < 0.0 ? -0.5 * PI : 0.5 * PI;
+    double z = ptmi_atan_d((y < 0.0 ? -y : y) / (x < 0.0 ? -x : x));
+    if (x > 0.0) return y < 0.0 ? -z : z;
+    z = PI - (z - PI_LO);
+    return y < 0.0 ? -z : z;
+}
+PTMI_HD float ptmi_atan2f(float y, float x) { return (float)ptmi_atan2_d((double)y, (double)x); }
+/* acosf for |x| <= 1 (callers clamp, grid.h:307): acos x = atan2(sqrt((1 - x)(1 + x)), x); both factors are exact
+ * in binary64 for a binary32 x */
+PTMI_HD float ptmi_acosf(float x) {
+    const double xd = (double)x;
+    return (float)ptmi_atan2_d(__builtin_sqrt((1.0 - xd) * (1.0 + xd)), xd);
+}
+
 #endif /* PTMI_MATH_H */

@@ -83,10 +83,29 @@ typedef struct {        /* bvh.h:63-72 */
     int left_child, right_child, prim_count;
 } onode;
 
+/* render_config.h:8-31: 16 x 16 directional grid, upper hemisphere = rows 0..7; PrecomputedCDF is 2120 bytes */
+#define GRID_RES 16
+#define GRID_SIZE (GRID_RES * GRID_RES)
+#define GRID_HALF_RES (GRID_RES / 2)
+#define GRID_INV_RES (1.0f / GRID_RES)
+#define GRID_INV_HALF_RES (1.0f / GRID_HALF_RES)
+#define GRID_D_THETA ((PTMI_PI_D * 0.5f) / GRID_HALF_RES)   /* double: M_PI is a double */
+#define GRID_D_PHI (2.0f * PTMI_PI_D / GRID_RES)
+typedef struct {
+    float pdf[GRID_SIZE];
+    float row_sums[GRID_HALF_RES];
+    float marginal_cdf[GRID_HALF_RES];
+    float row_cdfs[GRID_SIZE];
+    float total_weight;
+    int is_valid;
+} ocdf;
+
 struct po_scene {
     oprim* prims; int n_prims;
     onode* nodes; int n_nodes, cap_nodes;
     int* indices;
+    ocdf* cdfs;               /* Scene::precomputed_cdfs (scene.h:205), NULL until radiosity grids are supplied */
+    float mis_bsdf_fraction;  /* Scene::mis_bsdf_fraction, 0.5 (scene.h:217) */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -420,7 +439,7 @@ po_scene* po_scene_load(const char* path, int subdivision_count, int convert_qua
     if (convert_quads) convert_quads_to_triangles(&pv);
     if (subdivision_count > 0) subdivide_primitives(&pv, subdivision_count);
     po_scene* s = (po_scene*)calloc(1, sizeof *s);
-    s->prims = pv.p; s->n_prims = pv.n;
+    s->prims = pv.p; s->n_prims = pv.n; s->mis_bsdf_fraction = 0.5f;
     build_bvh(s);
     return s;
 }
@@ -428,6 +447,7 @@ po_scene* po_scene_load(const char* path, int subdivision_count, int convert_qua
 po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
                                const float* normal, const float* bsdf, const float* Le) {
     po_scene* s = (po_scene*)calloc(1, sizeof *s);
+    s->mis_bsdf_fraction = 0.5f;
     s->prims = (oprim*)calloc((size_t)(n > 0 ? n : 1), sizeof(oprim)); s->n_prims = n;
     for (int i = 0; i < n; i++) {
         oprim* p = &s->prims[i];
@@ -440,7 +460,55 @@ po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
     build_bvh(s);
     return s;
 }
-void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s); }
+void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s->cdfs); free(s); }
+
+/* SceneState::precomputeCDFs (application_state.h:492-585) from per-primitive radiosity grids
+ * (rgb: n_prims * 256 * 3 floats, load order).  The grids are an INPUT here: the O(N^2) radiosity
+ * solver that fills them in the reference (form_factors.h) is out of scope. */
+void po_scene_set_radiosity_grids(po_scene* s, const float* rgb) {
+    free(s->cdfs); s->cdfs = NULL;
+    if (!rgb) return;
+    s->cdfs = (ocdf*)calloc((size_t)s->n_prims, sizeof(ocdf));
+    for (int p = 0; p < s->n_prims; p++) {
+        ocdf* cdf = &s->cdfs[p];
+        const float* g = rgb + (size_t)p * GRID_SIZE * 3;
+        for (int i = 0; i < GRID_SIZE; i++)
+            cdf->pdf[i] = 0.2126f * g[3 * i] + 0.7152f * g[3 * i + 1] + 0.0722f * g[3 * i + 2];
+        cdf->total_weight = 0.0f;
+        for (int v = 0; v < GRID_HALF_RES; v++) {
+            float row_sum = 0.0f;
+            for (int u = 0; u < GRID_RES; u++) row_sum += cdf->pdf[v * GRID_RES + u];
+            cdf->row_sums[v] = row_sum;
+            cdf->total_weight += row_sum;
+        }
+        float running = 0.0f;
+        float inv_total = (cdf->total_weight > 1e-6f) ? (1.0f / cdf->total_weight) : 0.0f;
+        for (int v = 0; v < GRID_HALF_RES; v++) { running += cdf->row_sums[v]; cdf->marginal_cdf[v] = running * inv_total; }
+        cdf->marginal_cdf[GRID_HALF_RES - 1] = 1.0f;
+        for (int v = 0; v < GRID_HALF_RES; v++) {
+            const int ro = v * GRID_RES;
+            const float row_sum = cdf->row_sums[v];
+            if (row_sum < 1e-6f) {
+                for (int u = 0; u < GRID_RES; u++) cdf->row_cdfs[ro + u] = (u + 1) * GRID_INV_RES;
+            } else {
+                float running_row = 0.0f;
+                const float inv_row_sum = 1.0f / row_sum;
+                for (int u = 0; u < GRID_RES; u++) { running_row += cdf->pdf[ro + u]; cdf->row_cdfs[ro + u] = running_row * inv_row_sum; }
+                cdf->row_cdfs[ro + GRID_RES - 1] = 1.0f;
+            }
+        }
+        for (int v = GRID_HALF_RES; v < GRID_RES; v++)
+            for (int u = 0; u < GRID_RES; u++) cdf->row_cdfs[v * GRID_RES + u] = (u + 1) * GRID_INV_RES;
+        cdf->is_valid = (cdf->total_weight > 1e-6f) ? 1 : 0;
+    }
+}
+void po_scene_set_mis_fraction(po_scene* s, float f) { s->mis_bsdf_fraction = f; }
+/* out: n_prims * 530 floats (the PrecomputedCDF records, is_valid as an int bit pattern) */
+int po_scene_get_cdfs(const po_scene* s, float* out) {
+    if (!s->cdfs) return 0;
+    memcpy(out, s->cdfs, (size_t)s->n_prims * sizeof(ocdf));
+    return 1;
+}
 int po_scene_num_prims(const po_scene* s) { return s->n_prims; }
 int po_scene_num_nodes(const po_scene* s) { return s->n_nodes; }
 void po_scene_get_prims(const po_scene* s, int* type, float* verts, float* normal, float* bsdf, float* Le) {
@@ -593,6 +661,8 @@ int po_rng_selftest(int log2n, const uint32_t v_in[5]) {
 
 void po_sincosf(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }
 float po_powf(float x, float y) { return ptmi_powf(x, y); }
+float po_acosf(float x) { return ptmi_acosf(x); }
+float po_atan2f(float y, float x) { return ptmi_atan2f(y, x); }
 
 /* ------------------------------------------------------------------------ */
 /* triangle.h:64-96, quad.h:49-132, primitive.h:83-90                        */
@@ -750,9 +820,100 @@ void po_sample_cosine_hemisphere(const float n[3], float u, float v, float out[3
 }
 
 /* ------------------------------------------------------------------------ */
-/* integrator.h:189-268 integrator(), BSDF mode                               */
+/* rendering/grid.h: Grid over a PrecomputedCDF (loadPrecomputed path)         */
 /* ------------------------------------------------------------------------ */
-static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint32_t rng[6], counters* cn) {
+static void build_frame(v3 n, v3* t, v3* b) {   /* grid.h:287-297, same Frisvad frame as integrator.h:72-82 */
+    if (n.e[2] < -0.9999999f) { *t = V(0.0f, -1.0f, 0.0f); *b = V(-1.0f, 0.0f, 0.0f); return; }
+    const float a = 1.0f / (1.0f + n.e[2]);
+    const float c = -n.e[0] * n.e[1] * a;
+    *t = V(1.0f - n.e[0] * n.e[0] * a, c, -n.e[0]);
+    *b = V(c, 1.0f - n.e[1] * n.e[1] * a, -n.e[1]);
+}
+static int linear_search_cdf(const float* cdf, int size, float xi) {   /* grid.h:233-240 */
+    xi = fminf(fmaxf(xi, 0.0f), 0.999999f);
+    for (int i = 0; i < size; i++) if (xi < cdf[i]) return i;
+    return size - 1;
+}
+static float grid_pdf_for_cell(const ocdf* g, int theta_idx, int phi_idx) {   /* grid.h:242-253 */
+    const int idx = theta_idx * GRID_RES + phi_idx;
+    const float cell_value = g->pdf[idx];
+    if (cell_value < 1e-8f) return 1e-6f;
+    const float cell_prob = cell_value / fmaxf(g->total_weight, 1e-6f);
+    const float theta_center = (float)((double)((theta_idx + 0.5f) * GRID_INV_HALF_RES) * (PTMI_PI_D * 0.5f));
+    float st, ct; ptmi_sincosf(theta_center, &st, &ct);
+    const float sin_theta = fmaxf(st, 0.01f);
+    const float solid_angle = (float)(((double)sin_theta * GRID_D_THETA) * GRID_D_PHI);
+    return cell_prob / fmaxf(solid_angle, 1e-6f);
+}
+static v3 grid_sample(const ocdf* g, v3 normal, uint32_t rng[6], float* out_pdf) {   /* grid.h:141-188 (is_valid checked by the caller) */
+    const float xi1 = rng_uniform(rng);
+    const float xi2 = rng_uniform(rng);
+    const int theta_idx = linear_search_cdf(g->marginal_cdf, GRID_HALF_RES, xi1);
+    const int phi_idx = linear_search_cdf(&g->row_cdfs[theta_idx * GRID_RES], GRID_RES, xi2);
+    const float jitter_theta = rng_uniform(rng);
+    const float jitter_phi = rng_uniform(rng);
+    float theta = (float)((double)(((float)theta_idx + jitter_theta) * GRID_INV_HALF_RES) * (PTMI_PI_D * 0.5f));
+    theta = fminf(theta, (float)(PTMI_PI_D * 0.5f - (double)0.01f));
+    const float phi = (float)((double)((((float)phi_idx + jitter_phi) * GRID_INV_RES) * 2.0f) * PTMI_PI_D);
+    float sin_t, cos_t, sin_p, cos_p;
+    ptmi_sincosf(theta, &sin_t, &cos_t);
+    ptmi_sincosf(phi, &sin_p, &cos_p);
+    const v3 local = V(sin_t * cos_p, sin_t * sin_p, cos_t);
+    v3 tangent, bitangent; build_frame(normal, &tangent, &bitangent);
+    const v3 world = vunit(vadd(vadd(vscale(local.e[0], tangent), vscale(local.e[1], bitangent)), vscale(local.e[2], normal)));
+    *out_pdf = grid_pdf_for_cell(g, theta_idx, phi_idx);
+    return world;
+}
+static float grid_compute_pdf(const ocdf* g, v3 dir, v3 normal) {   /* grid.h:200-216 + worldToSpherical :299-310 */
+    v3 tangent, bitangent; build_frame(normal, &tangent, &bitangent);
+    const float lx = vdot(dir, tangent), ly = vdot(dir, bitangent), lz = vdot(dir, normal);
+    const float theta = ptmi_acosf(fminf(fmaxf(lz, -1.0f), 1.0f));
+    float phi = ptmi_atan2f(ly, lx);
+    if (phi < 0.0f) phi = (float)((double)phi + (double)2.0f * PTMI_PI_D);
+    if ((double)theta > PTMI_PI_D * 0.5f) return 0.0f;
+    int theta_idx = (int)(((double)theta * ((double)2.0f / PTMI_PI_D)) * GRID_HALF_RES);
+    int phi_idx = (int)(((double)phi * ((double)0.5f / PTMI_PI_D)) * GRID_RES);
+    theta_idx = theta_idx < 0 ? 0 : (theta_idx > GRID_HALF_RES - 1 ? GRID_HALF_RES - 1 : theta_idx);
+    phi_idx = phi_idx < 0 ? 0 : (phi_idx > GRID_RES - 1 ? GRID_RES - 1 : phi_idx);
+    return grid_pdf_for_cell(g, theta_idx, phi_idx);
+}
+static float mis_power_heuristic(float pdf_a, float pdf_b) {   /* integrator.h:91-96 */
+    if (pdf_a <= 0.0f) return 0.0f;
+    const float a2 = pdf_a * pdf_a, b2 = pdf_b * pdf_b;
+    return a2 / (a2 + b2);
+}
+static v3 sample_mis(const ocdf* g, v3 normal, uint32_t rng[6], float* weight, float bsdf_prob) {   /* integrator.h:112-167 */
+    const float BSDF_PROB = fmaxf(fminf(bsdf_prob, 0.99f), 0.01f);
+    const float GRID_PROB = 1.0f - BSDF_PROB;
+    const float xi = rng_uniform(rng);
+    v3 dir; float pdf_grid, pdf_bsdf, mis_w;
+    if (xi < BSDF_PROB) {
+        const float u = rng_uniform(rng), v = rng_uniform(rng);
+        dir = sample_cosine_hemisphere_uv(normal, u, v);
+        const float cos_theta = fmaxf(vdot(dir, normal), 0.0f);
+        pdf_bsdf = (float)((double)cos_theta / PTMI_PI_D);
+        pdf_grid = grid_compute_pdf(g, dir, normal);
+        mis_w = mis_power_heuristic(pdf_bsdf, pdf_grid);
+        *weight = (pdf_bsdf > 1e-6f) ? mis_w / BSDF_PROB : 0.0f;
+    } else {
+        dir = grid_sample(g, normal, rng, &pdf_grid);
+        const float cos_theta = fmaxf(vdot(dir, normal), 0.0f);
+        pdf_bsdf = (float)((double)cos_theta / PTMI_PI_D);
+        mis_w = mis_power_heuristic(pdf_grid, pdf_bsdf);
+        if (pdf_grid > 1e-6f && cos_theta > 0.0f) {
+            float w = (float)((double)(mis_w * cos_theta) / ((PTMI_PI_D * (double)pdf_grid) * (double)GRID_PROB));
+            *weight = fminf(w, 10.0f);
+        } else *weight = 0.0f;
+    }
+    return dir;
+}
+
+/* ------------------------------------------------------------------------ */
+/* integrator.h:189-268 integrator(), all sampling modes                      */
+/* ------------------------------------------------------------------------ */
+enum { SAMPLING_BSDF = 0, SAMPLING_FORMFACTOR = 1, SAMPLING_RADIOSITY = 2, SAMPLING_MIS = 3, SAMPLING_TOPK = 4 };   /* render_config.h:38-44 */
+
+static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint32_t rng[6], int mode, counters* cn) {
     v3 throughput = V(1.0f, 1.0f, 1.0f);
     ray_t r = ray;
     for (int depth = 0; depth < max_depth; depth++) {
@@ -774,9 +935,27 @@ static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint
         if (vlen(throughput) < 1e-5f) break;                                     /* :218 */
         v3 normal = p->normal;
         v3 shading_normal = vdot(r.d, normal) < 0 ? normal : vneg(normal);       /* :221-222 */
-        float u = rng_uniform(rng);                                              /* :63-64: u then v */
-        float v = rng_uniform(rng);
-        v3 next_dir = sample_cosine_hemisphere_uv(shading_normal, u, v);         /* :230 */
+        v3 next_dir;
+        /* initGridFromPrimitive (:31-57): with precomputed CDFs the grid is the primitive's record; without them the
+         * raw radiosity grid of a freshly loaded primitive is all zero, so the grid is invalid either way and the
+         * branch below falls back to cosine sampling (:258-261) with the same two draws as the BSDF mode */
+        const ocdf* g = (mode != SAMPLING_BSDF && sc->cdfs && sc->cdfs[prim].is_valid) ? &sc->cdfs[prim] : NULL;
+        if (g && mode == SAMPLING_MIS) {                                         /* :238-241 */
+            float weight = 1.0f;
+            next_dir = sample_mis(g, shading_normal, rng, &weight, sc->mis_bsdf_fraction);
+            throughput = V(throughput.e[0] * weight, throughput.e[1] * weight, throughput.e[2] * weight);
+        } else if (g) {                                                          /* :242-257 pure grid sampling */
+            float grid_pdf;
+            next_dir = grid_sample(g, shading_normal, rng, &grid_pdf);
+            const float cos_theta = fmaxf(vdot(next_dir, shading_normal), 0.0f);
+            float weight = (float)((double)cos_theta / (PTMI_PI_D * (double)fmaxf(grid_pdf, 1e-6f)));
+            weight = fminf(fmaxf(weight, 0.0f), 10.0f);
+            throughput = V(throughput.e[0] * weight, throughput.e[1] * weight, throughput.e[2] * weight);
+        } else {
+            float u = rng_uniform(rng);                                          /* :63-64: u then v */
+            float v = rng_uniform(rng);
+            next_dir = sample_cosine_hemisphere_uv(shading_normal, u, v);        /* :230 / :260 */
+        }
         r = make_ray(vadd(si_p, vscale(1e-4f, shading_normal)), next_dir);       /* :266 */
     }
 }
@@ -786,7 +965,7 @@ static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint
 /* ------------------------------------------------------------------------ */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-int po_render(const po_scene* sc, const po_camera* cam, int width, int height, int spp, int max_depth,
+int po_render(const po_scene* sc, const po_camera* cam, int width, int height, int spp, int max_depth, int sampling_mode,
               uint64_t seed_base, int reset_rng, uint32_t* rng_state,
               int y0, int y1, int n_threads,
               unsigned char* out_rgb8, float* out_radiance, po_stats* stats) {
@@ -828,7 +1007,7 @@ int po_render(const po_scene* sc, const po_camera* cam, int width, int height, i
                 float v = ((float)y + rng_uniform(rng)) / (float)height;   /* :385 */
                 ray_t ray = camera_get_ray(&cf, u, v);
                 v3 sample_color = V(0.0f, 0.0f, 0.0f);
-                integrator(sc, ray, &sample_color, max_depth, rng, &cn);
+                integrator(sc, ray, &sample_color, max_depth, rng, sampling_mode, &cn);
                 color = vadd(color, sample_color);
             }
             {   /* color /= float(spp) : vector.h:90-94 */

@@ -52,6 +52,12 @@ int po_scene_num_nodes(const po_scene*);
 void po_scene_get_prims(const po_scene*, int* type, float* verts, float* normal, float* bsdf, float* Le);
 void po_scene_get_bvh(const po_scene*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
 
+/* guided sampling inputs: per-primitive 16x16 radiosity grids, rgb = n_prims*256*3 floats in load
+ * order (NULL removes them); precomputeCDFs (application_state.h:492-585) turns them into the 2120-byte records */
+void po_scene_set_radiosity_grids(po_scene*, const float* rgb);
+void po_scene_set_mis_fraction(po_scene*, float f);
+int po_scene_get_cdfs(const po_scene*, float* out /* n_prims * 530 floats */);
+
 /* camera, rng, numerics -------------------------------------------------- */
 void po_camera_frame_setup(const po_camera*, int width, int height, po_camera_frame* out);
 void po_camera_ray(const po_camera_frame*, float u, float v, float o[3], float d[3]);
@@ -60,6 +66,8 @@ float po_rng_uniform(uint32_t state[6]);
 int po_rng_selftest(int log2n, const uint32_t v_in[5]);
 void po_sincosf(float x, float* s, float* c);
 float po_powf(float x, float y);
+float po_acosf(float x);
+float po_atan2f(float y, float x);
 void po_sample_cosine_hemisphere(const float n[3], float u, float v, float out[3]);
 
 /* intersection ------------------------------------------------------------ */
@@ -72,7 +80,7 @@ void po_intersect(const po_scene*, const float o[3], const float d[3], float t_m
  * rows are written.  rng_state: optional width*height*6 uint32 persistent
  * state; if NULL or reset_rng != 0 the state is (re)initialised as render_init
  * does.  n_threads <= 0: all cores. */
-int po_render(const po_scene*, const po_camera*, int width, int height, int spp, int max_depth,
+int po_render(const po_scene*, const po_camera*, int width, int height, int spp, int max_depth, int sampling_mode,
               uint64_t seed_base, int reset_rng, uint32_t* rng_state,
               int y0, int y1, int n_threads,
               unsigned char* out_rgb8, float* out_radiance, po_stats* stats);

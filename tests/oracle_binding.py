@@ -88,7 +88,12 @@ def oracle_lib():
         L.po_sample_cosine_hemisphere.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.po_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.POINTER(Hit)]
         L.po_render.restype = C.c_int
-        L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int,
+        L.po_scene_set_radiosity_grids.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_scene_set_mis_fraction.argtypes = [C.c_void_p, C.c_float]
+        L.po_scene_get_cdfs.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_acosf.restype = C.c_float; L.po_acosf.argtypes = [C.c_float]
+        L.po_atan2f.restype = C.c_float; L.po_atan2f.argtypes = [C.c_float, C.c_float]
+        L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         _oracle = L
@@ -152,13 +157,28 @@ class OracleScene:
         self.L.po_intersect(self.h, o.ctypes.data, d.ctypes.data, t_min, t_max, int(use_bvh), C.byref(h))
         return h
 
+    def set_radiosity_grids(self, rgb):
+        """rgb: (n_prims, 256, 3) float32 or None"""
+        if rgb is None:
+            self.L.po_scene_set_radiosity_grids(self.h, None); return
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        assert rgb.shape == (self.n_prims, 256, 3)
+        self.L.po_scene_set_radiosity_grids(self.h, rgb.ctypes.data)
+
+    def set_mis_fraction(self, f):
+        self.L.po_scene_set_mis_fraction(self.h, float(f))
+
+    def cdfs(self):
+        out = np.zeros((self.n_prims, 530), np.float32)
+        return out if self.L.po_scene_get_cdfs(self.h, out.ctypes.data) else None
+
     def render(self, cam, width, height, spp, max_depth=5, seed_base=2023, y0=0, y1=None, n_threads=0,
-               rng_state=None, reset_rng=True):
+               rng_state=None, reset_rng=True, sampling_mode=0):
         y1 = height if y1 is None else y1
         rgb = np.zeros((height, width, 3), np.uint8)
         rad = np.zeros((height, width, 3), np.float32)
         st = Stats()
-        rc = self.L.po_render(self.h, C.byref(cam), width, height, spp, max_depth, seed_base, int(reset_rng),
+        rc = self.L.po_render(self.h, C.byref(cam), width, height, spp, max_depth, int(sampling_mode), seed_base, int(reset_rng),
                               None if rng_state is None else rng_state.ctypes.data, y0, y1, n_threads,
                               rgb.ctypes.data, rad.ctypes.data, C.byref(st))
         if rc != 0:

@@ -344,3 +344,58 @@ def test_errors_are_reported_not_swallowed(R):
     with pytest.raises(ptmi.PtmiError):
         R.set_config(spp=0)
     R.set_config(spp=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# guided sampling modes: grid / MIS over per-primitive PrecomputedCDF records
+# ------------------------------------------------------------------------------------------------
+from guided_fixtures import synthetic_radiosity_grids  # noqa: E402
+
+
+@pytest.mark.parametrize("name,sub,conv,trav", [("cbox.obj", 0, False, -1), ("cbox_quads.obj", 0, False, -1),
+                                                ("cbox.obj", 1, False, -1), ("cbox.obj", 0, False, 1), ("cbox.obj", 2, False, 2)])
+@pytest.mark.parametrize("mode,frac", [(1, 0.5), (2, 0.5), (3, 0.5), (3, 0.2), (4, 0.5)])
+def test_guided_modes_match_oracle(R, name, sub, conv, trav, mode, frac):
+    path = os.path.join(SCENES, name)
+    R.load_scene(path, sub, conv)
+    R.set_traversal(trav)
+    o = OracleScene.load(path, sub, conv)
+    grids = synthetic_radiosity_grids(o.n_prims, seed=mode)
+    R.set_radiosity_grids(grids); o.set_radiosity_grids(grids); o.set_mis_fraction(frac)
+    assert (bits(R.precomputed_cdfs()) == bits(o.cdfs())).all()            # host precomputeCDFs == oracle, bit for bit
+    W, H, spp, depth = 64, 40, 6, 5
+    R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, sampling_mode=mode, mis_bsdf_fraction=frac, collect_stats=True)
+    try:
+        st = R.render_frame()
+        rgb, rad = R.read_image()
+        orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=depth, sampling_mode=mode)
+        assert_same_image(rgb, rad, orgb, orad, f"{name} mode {mode}")
+        assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        # and the guided frame really differs from the BSDF frame
+        R.update_resolution(W, H); R.set_config(sampling_mode=0)
+        R.render_frame()
+        assert (bits(R.read_image()[1]) != bits(rad)).any()
+    finally:
+        R.set_config(sampling_mode=0, mis_bsdf_fraction=0.5, collect_stats=False)
+        R.set_traversal(-1)
+
+
+def test_guided_modes_without_records_equal_bsdf(R):
+    R.load_scene(os.path.join(SCENES, "cbox.obj"))
+    R.update_resolution(64, 64); R.set_config(spp=4, max_depth=5, sampling_mode=0)
+    R.render_frame()
+    ref = R.read_image()
+    for mode in (1, 2, 3, 4):
+        R.update_resolution(64, 64); R.set_config(sampling_mode=mode)
+        R.render_frame()
+        got = R.read_image()
+        assert (bits(got[1]) == bits(ref[1])).all() and (got[0] == ref[0]).all(), mode
+    R.set_radiosity_grids(np.zeros((32, 256, 3), F))                       # records present, all invalid
+    R.update_resolution(64, 64); R.set_config(sampling_mode=3)
+    R.render_frame()
+    assert (bits(R.read_image()[1]) == bits(ref[1])).all()
+    with pytest.raises(ptmi.PtmiError):
+        R.set_radiosity_grids(np.zeros((31, 256, 3), F))                   # wrong primitive count
+    R.set_radiosity_grids(None)
+    R.set_config(sampling_mode=0)
