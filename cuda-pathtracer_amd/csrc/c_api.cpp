@@ -67,7 +67,7 @@ void ptmi_default_camera(ptmi_camera* c) {
 void ptmi_default_config(ptmi_config* c) {
     const AppConfig d;
     c->spp = d.spp; c->max_depth = d.max_depth; c->sampling_mode = (int)d.sampling_mode; c->seed_base = d.seed_base;
-    c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0; c->streams = 0; c->mis_bsdf_fraction = d.mis_bsdf_fraction;
+    c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0; c->streams = 0; c->mis_bsdf_fraction = d.mis_bsdf_fraction; c->integrator = 0;
 }
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
@@ -219,6 +219,15 @@ int ptmi_set_radiosity_grids(ptmi_ctx* c, int n_prims, const float* rgb) {
         c->app.scene.precomputeCDFs(rgb);
     });
 }
+int ptmi_set_radiosity(ptmi_ctx* c, int n_prims, const float* rgb) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(c->app.scene.d_nodes != nullptr, "no scene loaded");
+        need(rgb == nullptr || n_prims == (int)c->app.scene.h_primitives.size(), "n_prims does not match the loaded scene");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.scene.setRadiosity(rgb);
+    });
+}
 int ptmi_get_precomputed_cdfs(const ptmi_ctx* c, float* out) {
     return guarded([&] {
         need(c && out, "NULL argument");
@@ -260,10 +269,12 @@ int ptmi_set_config(ptmi_ctx* c, const ptmi_config* cfg) {
         need(cfg->max_depth >= 1 && cfg->max_depth <= 255, "max_depth must be in [1, 255]");
         need(cfg->sampling_mode >= 0 && cfg->sampling_mode <= 4, "sampling_mode must be 0..4 (render_config.h:38-44)");
         need(cfg->mis_bsdf_fraction >= 0.0f && cfg->mis_bsdf_fraction <= 1.0f, "mis_bsdf_fraction must be in [0, 1]");
+        need(cfg->integrator == 0 || cfg->integrator == 1, "integrator must be 0 (PathTracing) or 1 (Radiosity)");
         need(cfg->segments_per_launch >= 0, "segments_per_launch must be >= 0");
         AppConfig& a = c->app.config;
         a.spp = cfg->spp; a.max_depth = cfg->max_depth; a.sampling_mode = (SamplingMode)cfg->sampling_mode;
         a.mis_bsdf_fraction = cfg->mis_bsdf_fraction;
+        a.current_integrator = cfg->integrator ? IntegratorType::Radiosity : IntegratorType::PathTracing;
         a.seed_base = cfg->seed_base; a.segments_per_launch = cfg->segments_per_launch; a.collect_stats = cfg->collect_stats != 0;
         need(cfg->streams >= 0 && cfg->streams <= RenderState::kMaxChunks, "streams must be 0..4");
         c->app.render.allow_tile8 = cfg->wave_tiles != 0;

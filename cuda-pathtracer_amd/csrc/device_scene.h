@@ -47,6 +47,9 @@ struct DeviceScene {
     // (render_config.h:24-31: pdf[256], row_sums[8], marginal_cdf[8], row_cdfs[256], total_weight, is_valid = 530
     // dwords = 2120 B), HBM/L2-resident, read per hit through the load-order index kept in mats[3k].w.  nullptr = none.
     const float* cdfs = nullptr;
+    // Per-primitive radiosity (Triangle/Quad::radiosity, the radiosity solver's output in the reference): float4 per
+    // LEAF-ORDER slot, read by ptmi_render_radiosity only.  nullptr = all zero (as after loading a scene).
+    const float4* radiosity = nullptr;
 };
 constexpr int kCdfDwords = 530, kCdfPdf = 0, kCdfRowSums = 256, kCdfMarginal = 264, kCdfRowCdfs = 272, kCdfTotal = 528, kCdfValid = 529;
 
@@ -97,6 +100,10 @@ void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParam
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */, hipStream_t s);
+// render_radiosity (integrator.h:460-504): the alternative "Radiosity" integrator of renderFrame (application.h:193-197):
+// spp camera rays per pixel, first hit only, Le + per-primitive radiosity, sqrt gamma, 8-bit (+ float mean).
+void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
+                             unsigned char* rgb8, float* radiance, hipStream_t s);
 // mean, Reinhard, gamma, 8-bit (integrator.h:393-407) + float radiance.
 void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s);
 

@@ -890,6 +890,64 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
 }
 
 // ---------------------------------------------------------------------------------------------
+// render_radiosity (integrator.h:460-504): a visualisation pass, one thread per pixel, not performance-critical
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool HAS_QUADS>
+__global__ __launch_bounds__(kBlock) void ptmi_render_radiosity(DeviceScene sc, TileMap tm, PathState st, FrameParams fp,
+                                                                unsigned char* __restrict__ rgb8, float* __restrict__ radiance) {
+    extern __shared__ float4 smem[];
+    int* stack = reinterpret_cast<int*>(smem) + threadIdx.x;
+    const int n = tm.local_rows * tm.width;
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = slot < n;
+    int x = 0, y = 0;
+    Rng rng = {0, 0, 0, 0, 0, 0};
+    if (live) {
+        global_pixel(tm, slot, x, y);
+        const uint4 e = st.E[slot]; const uint2 f = st.F[slot];
+        rng = Rng{e.x, e.y, e.z, e.w, f.x, f.y};                                      // curandState local_rng = rand_state[pixel_index]
+    }
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    LaneCounters cn = {0, 0, 0, 0};
+    for (int s = 0; s < fp.spp; s++) {
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+        if (live) camera_ray(fp, tm, x, y, rng, o, d);
+        float t = 0.0f; int k = -1;
+        const bool hit = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, o, d, 1e-4f, FLT_MAX, t, k, cn);
+        if (live && hit) {
+            color = color + xyz(sc.mats[3 * k + 2]);                                  // color += si.Le
+            color = color + (sc.radiosity ? xyz(sc.radiosity[k]) : mk3(0.0f, 0.0f, 0.0f));   // color += prim->getRadiosity()
+        }
+    }
+    if (!live) return;
+    const float kk = rcp_rn((float)fp.spp);
+    const float c[3] = {color.x * kk, color.y * kk, color.z * kk};
+    int ox, olr;
+    slot_to_local(tm, slot, ox, olr);
+    const size_t out = (size_t)olr * (size_t)tm.width + (size_t)ox;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        if (radiance) radiance[out * 3 + ch] = c[ch];
+        if (rgb8) rgb8[out * 3 + ch] = (unsigned char)(255.99f * sqrt_rn(fminf(c[ch], 1.0f)));
+    }
+    st.E[slot] = make_uint4(rng.v0, rng.v1, rng.v2, rng.v3);                          // rand_state[pixel_index] = local_rng
+    st.F[slot] = make_uint2(rng.v4, rng.d);
+}
+
+void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
+                             unsigned char* rgb8, float* radiance, hipStream_t s) {
+    const int n = tm.local_rows * tm.width;
+    if (n <= 0) return;
+    const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    const bool deep = sc.traversal == TRAVERSAL_STACK;                                // per-lane walk from global memory; stack only for deep trees
+    const size_t lds = deep ? (size_t)sc.stack_entries * kBlock * sizeof(int) : 0;
+#define PTMI_RAD(M_, Q_) hipLaunchKernelGGL((ptmi_render_radiosity<M_, Q_>), grid, block, lds, s, sc, tm, st, fp, rgb8, radiance)
+    if (deep) { if (sc.has_quads) PTMI_RAD(TRAVERSAL_STACK, true); else PTMI_RAD(TRAVERSAL_STACK, false); }
+    else { if (sc.has_quads) PTMI_RAD(TRAVERSAL_LANE, true); else PTMI_RAD(TRAVERSAL_LANE, false); }
+#undef PTMI_RAD
+}
+
+// ---------------------------------------------------------------------------------------------
 // test hooks
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool HAS_QUADS>

@@ -83,7 +83,8 @@ void SceneState::cleanup() {
     if (d_prims) (void)hipFree(d_prims);
     if (d_mats) (void)hipFree(d_mats);
     if (d_precomputed_cdfs) (void)hipFree(d_precomputed_cdfs);
-    d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr;
+    if (d_radiosity) (void)hipFree(d_radiosity);
+    d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr; d_radiosity = nullptr;
     h_precomputed_cdfs.clear();
     d_scene = DeviceScene();
     h_primitives.clear(); bvh_nodes.clear(); bvh_indices.clear();
@@ -190,6 +191,22 @@ void SceneState::upload() {
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
     chooseTraversal();
+}
+
+void SceneState::setRadiosity(const float* rgb) {
+    if (!d_nodes) throw ArgError("setRadiosity: no scene loaded");
+    if (d_radiosity) { (void)hipFree(d_radiosity); d_radiosity = nullptr; }
+    d_scene.radiosity = nullptr;
+    if (!rgb) return;
+    const int n = (int)h_primitives.size();
+    std::vector<float4> leaf_order((size_t)n);
+    for (int k = 0; k < n; k++) {                    // same leaf-order slots as prims/mats
+        const float* c = rgb + (size_t)bvh_indices[k] * 3;
+        leaf_order[k] = make_float4(c[0], c[1], c[2], 0.0f);
+    }
+    d_radiosity = (float4*)hipMallocSafe(leaf_order.size() * sizeof(float4), "d_radiosity");
+    PTMI_HIP(hipMemcpy(d_radiosity, leaf_order.data(), leaf_order.size() * sizeof(float4), hipMemcpyHostToDevice));
+    d_scene.radiosity = d_radiosity;
 }
 
 void SceneState::precomputeCDFs(const float* rgb) {
@@ -386,6 +403,22 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     const hipEvent_t ev_begin = event(n_ev++);
     PTMI_HIP(hipEventRecord(ev_begin, s));
     if (want_stats) PTMI_HIP(hipMemsetAsync(r.d_stats, 0, sizeof(StatCounters), s));
+
+    if (g.config.current_integrator == IntegratorType::Radiosity) {       // application.h:193-197
+        launch_render_radiosity(g.scene.d_scene, r.tile, r.d_state, fp, r.d_image, r.d_radiance, s);
+        PTMI_HIP(hipGetLastError());
+        const hipEvent_t ev_done = event(n_ev++);
+        PTMI_HIP(hipEventRecord(ev_done, s));
+        PTMI_HIP(hipStreamSynchronize(s));
+        if (stats) {
+            float ms = 0.0f;
+            PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_done));
+            *stats = FrameStats();
+            stats->seconds = ms * 1e-3;
+            stats->samples = (uint64_t)n_local * (uint64_t)g.config.spp;
+        }
+        return;
+    }
 
     launch_frame_begin(r.tile, r.d_state, fp, s);
 

@@ -31,6 +31,7 @@ struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; 
 // cudaMallocSafe (utils/cuda_utils.h:54-60): throws on failure
 void* hipMallocSafe(size_t bytes, const char* name);
 
+enum class IntegratorType { PathTracing = 0, Radiosity = 1 };                       // application_state.h:50-53
 enum class SamplingMode { SAMPLING_BSDF = 0, SAMPLING_FORMFACTOR = 1, SAMPLING_RADIOSITY = 2, SAMPLING_MIS = 3, SAMPLING_TOPK = 4 };   // render_config.h:38-44
 
 struct AppConfig {                                   // application_state.h:262-293 (path-relevant members)
@@ -45,6 +46,7 @@ struct AppConfig {                                   // application_state.h:262-
     int segments_per_launch = 0;                     // 0 = default
     bool collect_stats = false;
     float mis_bsdf_fraction = 0.5f;                  // application_state.h:292 / scene.h:217
+    IntegratorType current_integrator = IntegratorType::PathTracing;   // application_state.h:283
 };
 
 struct SceneState {
@@ -64,6 +66,9 @@ struct SceneState {
     // order; nullptr drops the records).  The radiosity solver that fills the grids in the reference is out of scope:
     // the grids are an input.
     void precomputeCDFs(const float* radiosity_grids_rgb);
+    // per-primitive radiosity for the Radiosity integrator (render_radiosity); n_prims*3 floats, load order; nullptr = zero
+    float4* d_radiosity = nullptr;
+    void setRadiosity(const float* rgb);
     int sweep_max_prims = 64;                        // scenes up to this many primitives use the wave-uniform sweep
     int force_traversal = -1;                        // test/benchmark override (TraversalMode), -1 = automatic
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "ptmi_default_tiling", "ptmi_load_scene", "ptmi_load_scene_arrays", "ptmi_scene_info", "ptmi_scene_get_prims",
     "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
     "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
-    "ptmi_copy_image_device", "ptmi_set_radiosity_grids", "ptmi_get_precomputed_cdfs",
+    "ptmi_copy_image_device", "ptmi_set_radiosity_grids", "ptmi_get_precomputed_cdfs", "ptmi_set_radiosity",
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
@@ -34,7 +34,7 @@ class Camera(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("spp", C.c_int), ("max_depth", C.c_int), ("sampling_mode", C.c_int), ("seed_base", C.c_uint64),
-                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int), ("mis_bsdf_fraction", C.c_float)]
+                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int), ("mis_bsdf_fraction", C.c_float), ("integrator", C.c_int)]
 
 
 class Tiling(C.Structure):
@@ -88,6 +88,7 @@ def lib():
         L.ptmi_copy_image_device.argtypes = [vp, vp, vp]
         L.ptmi_set_radiosity_grids.argtypes = [vp, C.c_int, vp]
         L.ptmi_get_precomputed_cdfs.argtypes = [vp, vp]
+        L.ptmi_set_radiosity.argtypes = [vp, C.c_int, vp]
         L.ptmi_debug_intersect.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
         L.ptmi_debug_rng.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_int, vp]
         L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -227,6 +228,14 @@ class Renderer:
         assert rgb.ndim == 3 and rgb.shape[1:] == (256, 3)
         self._ck(self.L.ptmi_set_radiosity_grids(self.h, rgb.shape[0], rgb.ctypes.data))
 
+    def set_radiosity(self, rgb):
+        """rgb: (n_prims, 3) float32 per-primitive radiosity in load order, or None (zero)."""
+        if rgb is None:
+            self._ck(self.L.ptmi_set_radiosity(self.h, 0, None)); return
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        assert rgb.ndim == 2 and rgb.shape[1] == 3
+        self._ck(self.L.ptmi_set_radiosity(self.h, rgb.shape[0], rgb.ctypes.data))
+
     def precomputed_cdfs(self):
         out = np.zeros((self.scene_info()["n_prims"], 530), np.float32)
         self._ck(self.L.ptmi_get_precomputed_cdfs(self.h, out.ctypes.data))
@@ -262,7 +271,7 @@ class Renderer:
         self._ck(self.L.ptmi_set_camera(self.h, C.byref(cam)))
 
     def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None, wave_tiles=None, streams=None,
-                   sampling_mode=None, mis_bsdf_fraction=None):
+                   sampling_mode=None, mis_bsdf_fraction=None, integrator=None):
         c = self.config
         if spp is not None: c.spp = int(spp)
         if max_depth is not None: c.max_depth = int(max_depth)
@@ -273,6 +282,7 @@ class Renderer:
         if streams is not None: c.streams = int(streams)
         if sampling_mode is not None: c.sampling_mode = int(sampling_mode)
         if mis_bsdf_fraction is not None: c.mis_bsdf_fraction = float(mis_bsdf_fraction)
+        if integrator is not None: c.integrator = int(integrator)
         self._ck(self.L.ptmi_set_config(self.h, C.byref(c)))
 
     def camera_frame(self):

@@ -80,6 +80,9 @@ typedef struct {
      * pixels, else 1), 1 = single stream.  Takes effect at the next ptmi_update_resolution. */
     int      streams;
     float    mis_bsdf_fraction;   /* AppConfig::mis_bsdf_fraction, 0.5 (application_state.h:292) */
+    int      integrator;          /* AppConfig::current_integrator (application_state.h:50-53, 283): 0 = PathTracing,
+                                   * 1 = Radiosity: renderFrame launches render_radiosity (integrator.h:460-504) - first hit,
+                                   * Le + per-primitive radiosity, sqrt gamma - instead of the path tracer */
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).
@@ -134,6 +137,9 @@ int ptmi_scene_get_bvh(const ptmi_ctx*, float* bmin, float* bmax, int* left, int
 int ptmi_set_radiosity_grids(ptmi_ctx*, int n_prims, const float* rgb);
 /* host copy of the records, n_prims * 530 dwords (is_valid as an int bit pattern); returns PTMI_E_INVALID if there are none */
 int ptmi_get_precomputed_cdfs(const ptmi_ctx*, float* out);
+/* Per-primitive radiosity (Triangle/Quad::radiosity; n_prims * 3 floats, load order; NULL = zero) shown by the Radiosity
+ * integrator.  Like the grids above it is the radiosity solver's output in the reference and an input here. */
+int ptmi_set_radiosity(ptmi_ctx*, int n_prims, const float* rgb);
 
 /* ---- RenderState::allocateBuffers / updateResolution (application_state.h:91-129)
  * (Re)allocates the image, path-state and RNG buffers for this rank's rows of a

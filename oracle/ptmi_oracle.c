@@ -105,6 +105,7 @@ struct po_scene {
     onode* nodes; int n_nodes, cap_nodes;
     int* indices;
     ocdf* cdfs;               /* Scene::precomputed_cdfs (scene.h:205), NULL until radiosity grids are supplied */
+    v3* radiosity;            /* Triangle/Quad::radiosity per primitive (triangle.h:103), NULL = all zero (as after loading) */
     float mis_bsdf_fraction;  /* Scene::mis_bsdf_fraction, 0.5 (scene.h:217) */
 };
 
@@ -460,7 +461,14 @@ po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
     build_bvh(s);
     return s;
 }
-void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s->cdfs); free(s); }
+void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s->cdfs); free(s->radiosity); free(s); }
+/* per-primitive radiosity (n_prims * 3 floats, load order; NULL = zero): in the reference the radiosity solver's output */
+void po_scene_set_radiosity(po_scene* s, const float* rgb) {
+    free(s->radiosity); s->radiosity = NULL;
+    if (!rgb) return;
+    s->radiosity = (v3*)malloc(sizeof(v3) * (size_t)s->n_prims);
+    for (int i = 0; i < s->n_prims; i++) s->radiosity[i] = V(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
 
 /* SceneState::precomputeCDFs (application_state.h:492-585) from per-primitive radiosity grids
  * (rgb: n_prims * 256 * 3 floats, load order).  The grids are an INPUT here: the O(N^2) radiosity
@@ -961,7 +969,7 @@ static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint
 }
 
 /* ------------------------------------------------------------------------ */
-/* integrator.h:371-408 render kernel                                        */
+/* integrator.h:371-408 render kernel (po_render) and :460-504 render_radiosity */
 /* ------------------------------------------------------------------------ */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
@@ -1034,6 +1042,48 @@ int po_render(const po_scene* sc, const po_camera* cam, int width, int height, i
         stats->samples = (uint64_t)width * (uint64_t)(y1 - y0) * (uint64_t)spp;
         stats->rays = total.rays; stats->node_visits = total.node_visits;
         stats->prim_tests = total.prim_tests; stats->hits = total.hits;
+    }
+    return 0;
+}
+
+/* render_radiosity (integrator.h:460-504): first hit only, Le + per-primitive radiosity, sqrt "gamma".  Same frame /
+ * row / RNG conventions as po_render; out_radiance receives color / spp before the sqrt. */
+int po_render_radiosity(const po_scene* sc, const po_camera* cam, int width, int height, int spp,
+                        uint64_t seed_base, int reset_rng, uint32_t* rng_state, int y0, int y1, int n_threads,
+                        unsigned char* out_rgb8, float* out_radiance) {
+    if (!sc || width <= 0 || height <= 0 || spp <= 0 || y0 < 0 || y1 > height || y0 > y1) return -1;
+    init_jump_tables();
+    po_camera_frame cf; po_camera_frame_setup(cam, width, height, &cf);
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_num_procs();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+    for (int y = y0; y < y1; y++) {
+        counters cn = {0, 0, 0, 0};
+        for (int x = 0; x < width; x++) {
+            const int pixel_index = y * width + x;
+            uint32_t local[6];
+            if (rng_state && !reset_rng) memcpy(local, &rng_state[(size_t)pixel_index * 6], sizeof local);   /* :468 local copy */
+            else po_rng_init(seed_base + (uint64_t)pixel_index, (uint64_t)pixel_index, local);
+            v3 color = V(0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < spp; s++) {
+                const float u = ((float)x + rng_uniform(local)) / (float)width;
+                const float v = ((float)y + rng_uniform(local)) / (float)height;
+                const ray_t ray = camera_get_ray(&cf, u, v);
+                float t; int prim = -1;
+                if (scene_intersect_bvh(sc, &ray, 1e-4f, FLT_MAX, &t, &prim, &cn)) {
+                    color = vadd(color, sc->prims[prim].Le);                                                 /* :481 */
+                    color = vadd(color, sc->radiosity ? sc->radiosity[prim] : V(0.0f, 0.0f, 0.0f));          /* :483 */
+                }
+            }
+            { const float k = recip_via_double((float)spp); color = V(color.e[0] * k, color.e[1] * k, color.e[2] * k); }
+            if (out_radiance) for (int c = 0; c < 3; c++) out_radiance[(size_t)pixel_index * 3 + c] = color.e[c];
+            if (out_rgb8) for (int c = 0; c < 3; c++)
+                out_rgb8[(size_t)pixel_index * 3 + c] = (unsigned char)(255.99f * sqrtf(fminf(color.e[c], 1.0f)));   /* :492-501 */
+            if (rng_state) memcpy(&rng_state[(size_t)pixel_index * 6], local, sizeof local);                 /* :503 */
+        }
     }
     return 0;
 }

@@ -85,6 +85,12 @@ int po_render(const po_scene*, const po_camera*, int width, int height, int spp,
               int y0, int y1, int n_threads,
               unsigned char* out_rgb8, float* out_radiance, po_stats* stats);
 
+/* render_radiosity (integrator.h:460-504): first-hit Le + per-primitive radiosity, sqrt gamma */
+void po_scene_set_radiosity(po_scene*, const float* rgb /* n_prims*3, load order; NULL = zero */);
+int po_render_radiosity(const po_scene*, const po_camera*, int width, int height, int spp,
+                        uint64_t seed_base, int reset_rng, uint32_t* rng_state, int y0, int y1, int n_threads,
+                        unsigned char* out_rgb8, float* out_radiance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,10 @@ def oracle_lib():
         L.po_scene_set_radiosity_grids.argtypes = [C.c_void_p, C.c_void_p]
         L.po_scene_set_mis_fraction.argtypes = [C.c_void_p, C.c_float]
         L.po_scene_get_cdfs.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_scene_set_radiosity.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_render_radiosity.restype = C.c_int
+        L.po_render_radiosity.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.po_acosf.restype = C.c_float; L.po_acosf.argtypes = [C.c_float]
         L.po_atan2f.restype = C.c_float; L.po_atan2f.argtypes = [C.c_float, C.c_float]
         L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -164,6 +168,23 @@ class OracleScene:
         rgb = np.ascontiguousarray(rgb, np.float32)
         assert rgb.shape == (self.n_prims, 256, 3)
         self.L.po_scene_set_radiosity_grids(self.h, rgb.ctypes.data)
+
+    def set_radiosity(self, rgb):
+        if rgb is None:
+            self.L.po_scene_set_radiosity(self.h, None); return
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        assert rgb.shape == (self.n_prims, 3)
+        self.L.po_scene_set_radiosity(self.h, rgb.ctypes.data)
+
+    def render_radiosity(self, cam, width, height, spp, seed_base=2023, y0=0, y1=None, n_threads=0, rng_state=None, reset_rng=True):
+        y1 = height if y1 is None else y1
+        rgb = np.zeros((height, width, 3), np.uint8); rad = np.zeros((height, width, 3), np.float32)
+        rc = self.L.po_render_radiosity(self.h, C.byref(cam), width, height, spp, seed_base, int(reset_rng),
+                                        None if rng_state is None else rng_state.ctypes.data, y0, y1, n_threads,
+                                        rgb.ctypes.data, rad.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"po_render_radiosity failed: {rc}")
+        return rgb, rad
 
     def set_mis_fraction(self, f):
         self.L.po_scene_set_mis_fraction(self.h, float(f))
