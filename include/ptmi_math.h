@@ -149,6 +149,15 @@ PTMI_HD float ptmi_powf(float x, float y) {
     return (float)ptmi_exp_d((double)y * l);
 }
 
+/* expf(x) replacement for the grid filters' Gaussian weights (grid_filter.h:35-37): any float x.
+ * exp(-104) < 2^-150 (half the smallest denormal), exp(88.73) > FLT_MAX. */
+PTMI_HD float ptmi_expf(float x) {
+    if (x != x) return x;
+    if (x < -104.0f) return 0.0f;
+    if (x > 88.75f) return __builtin_inff();
+    return (float)ptmi_exp_d((double)x);
+}
+
 /* ---- atan / atan2 / acos in binary64 (grid.h:307-308 worldToSpherical uses acosf / atan2f) ------------------
  * fdlibm s_atan.c reduction and minimax polynomial (error < 1 ulp of binary64), IEEE binary64 sqrt for acos;
  * as everywhere in this file: no fma, results rounded once to binary32 by the float wrappers. */

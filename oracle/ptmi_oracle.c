@@ -971,6 +971,323 @@ static void integrator(const po_scene* sc, ray_t ray, v3* L, int max_depth, uint
 /* ------------------------------------------------------------------------ */
 /* integrator.h:371-408 render kernel (po_render) and :460-504 render_radiosity */
 /* ------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------ */
+/* the radiosity pre-pass.  RadiosityState::runSolver            */
+/* (application_state.h:688-777) and its kernels (form_factors.h:71-467,       */
+/* grid_filter.h:35-312).  Restated; form_factors.h/grid_filter.h include      */
+/* <cuda_runtime.h>/<curand_kernel.h> and cannot be compiled here, so this part */
+/* is pinned only through the pieces that live in primitive.h (area, centroid, */
+/* sampleUniform: checked against the compiled reference in                    */
+/* tests/test_oracle_vs_ref.py) and by properties (tests/test_radiosity_solver).*/
+/*                                                                            */
+/* Two places where the reference is not a function of its inputs:            */
+/*  - radiosity_iteration_kernel (form_factors.h:441-465) reads unshot_rad of  */
+/*    every j while other threads of the same launch overwrite theirs: a race. */
+/*    Restated with the evident intent (all reads see the previous iteration). */
+/*  - calculate_form_factors_mc_kernel adds per-pair partial sums to            */
+/*    radiosity_grid with float atomics in arbitrary order (:344-351).  Every   */
+/*    iteration's update_radiosity_grid overwrites that grid, so it only       */
+/*    survives with num_iterations == 0; canonical order here: ascending j.    */
+/*    (The count grid `grid` sums integers and is exact in any order.)         */
+/* ------------------------------------------------------------------------ */
+static float prim_area(const oprim* p) {   /* triangle.h:28,54 / quad.h:31 */
+    if (p->type == PRIM_TRIANGLE)
+        return 0.5f * vlen(vcross(vsub(p->v[1], p->v[0]), vsub(p->v[2], p->v[0])));
+    const v3 edge1 = vsub(p->v[1], p->v[0]), edge2 = vsub(p->v[3], p->v[0]);
+    return 0.5f * (vlen(vcross(edge1, edge2)) + vlen(vcross(vsub(p->v[2], p->v[1]), vsub(p->v[2], p->v[3]))));
+}
+static v3 bary_point(v3 a, v3 b, v3 c, float r1, float r2) {   /* primitive.h:153-157 */
+    const float sqrt_r1 = sqrtf(r1);
+    const float u = 1.0f - sqrt_r1;
+    const float v = sqrt_r1 * (1.0f - r2);
+    const float w = sqrt_r1 * r2;
+    return vadd(vadd(vscale(u, a), vscale(v, b)), vscale(w, c));
+}
+static v3 prim_sample_uniform(const oprim* p, float r1, float r2) {   /* primitive.h:150-191 */
+    if (p->type == PRIM_TRIANGLE) return bary_point(p->v[0], p->v[1], p->v[2], r1, r2);
+    const v3 v00 = p->v[0], v10 = p->v[1], v11 = p->v[2], v01 = p->v[3];
+    const float area1 = 0.5f * vlen(vcross(vsub(v10, v00), vsub(v01, v00)));
+    const float area2 = 0.5f * vlen(vcross(vsub(v11, v10), vsub(v11, v01)));
+    const float total_area = area1 + area2;
+    const float area_ratio = area1 / total_area;
+    if (r1 < area_ratio) return bary_point(v00, v10, v01, r1 / area_ratio, r2);
+    return bary_point(v10, v11, v01, (r1 - area_ratio) / (1.0f - area_ratio), r2);
+}
+void po_prim_geometry(const po_scene* s, int i, float* area, float centroid[3]) {
+    *area = prim_area(&s->prims[i]);
+    const v3 c = prim_centroid(&s->prims[i]);
+    memcpy(centroid, c.e, sizeof c.e);
+}
+void po_prim_sample_uniform(const po_scene* s, int i, float r1, float r2, float out[3]) {
+    const v3 p = prim_sample_uniform(&s->prims[i], r1, r2);
+    memcpy(out, p.e, sizeof p.e);
+}
+
+/* form_factors.h:107-130 direction_to_grid_indices_local: theta over [0, pi] -> 16 rows, phi over [0, 2 pi) -> 16 columns */
+static int direction_to_grid_index_local(v3 world_dir, v3 normal) {
+    v3 tangent, bitangent; build_frame(normal, &tangent, &bitangent);   /* form_factors.h:93-103 == grid.h:287-297 */
+    const float lx = vdot(world_dir, tangent), ly = vdot(world_dir, bitangent), lz = vdot(world_dir, normal);
+    const float r = sqrtf(lx * lx + ly * ly + lz * lz);
+    const float theta = (r > 0.0f) ? ptmi_acosf(fminf(lz / r, 1.0f)) : 0.0f;
+    float phi = ptmi_atan2f(ly, lx);
+    if (phi < 0.0f) phi = (float)((double)phi + (double)2.0f * PTMI_PI_D);
+    int grid_theta = (int)fminf((float)(((double)theta / PTMI_PI_D) * GRID_RES), (float)(GRID_RES - 1));
+    int grid_phi = (int)fminf((float)(((double)phi / ((double)2.0f * PTMI_PI_D)) * GRID_RES), (float)(GRID_RES - 1));
+    grid_theta = grid_theta < 0 ? 0 : (grid_theta > GRID_RES - 1 ? GRID_RES - 1 : grid_theta);
+    grid_phi = grid_phi < 0 ? 0 : (grid_phi > GRID_RES - 1 ? GRID_RES - 1 : grid_phi);
+    return grid_theta * GRID_RES + grid_phi;
+}
+int po_direction_to_grid_index(const float dir[3], const float normal[3]) {
+    return direction_to_grid_index_local(V(dir[0], dir[1], dir[2]), V(normal[0], normal[1], normal[2]));
+}
+
+/* form_factors.h:143-208 visibility_test_anyhit: its own traversal (32-entry stack, children dropped from 30 on,
+ * left pushed first so the right child is visited first, guarded reciprocals, EPSILON 1e-5) */
+static int visibility_test_anyhit(const po_scene* sc, const ray_t* r, float max_dist, int source_idx, int target_idx) {
+    const float EPSILON = 1e-5f;
+    int stack[32]; int stack_ptr = 0;
+    stack[stack_ptr++] = 0;
+    float inv_dir[3];
+    for (int a = 0; a < 3; a++) inv_dir[a] = 1.0f / (fabsf(r->d.e[a]) > 1e-8f ? r->d.e[a] : 1e-8f);
+    while (stack_ptr > 0) {
+        const int node_idx = stack[--stack_ptr];
+        const onode* node = &sc->nodes[node_idx];
+        float t1 = (node->bmin.e[0] - r->o.e[0]) * inv_dir[0];
+        float t2 = (node->bmax.e[0] - r->o.e[0]) * inv_dir[0];
+        float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
+        t1 = (node->bmin.e[1] - r->o.e[1]) * inv_dir[1];
+        t2 = (node->bmax.e[1] - r->o.e[1]) * inv_dir[1];
+        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        t1 = (node->bmin.e[2] - r->o.e[2]) * inv_dir[2];
+        t2 = (node->bmax.e[2] - r->o.e[2]) * inv_dir[2];
+        tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        if (tmax < EPSILON || tmin > max_dist || tmin > tmax) continue;
+        if (node->prim_count > 0) {
+            for (int i = 0; i < node->prim_count; i++) {
+                const int prim_idx = sc->indices[node->left_child + i];
+                if (prim_idx == source_idx || prim_idx == target_idx) continue;
+                float t;
+                if (prim_intersect(&sc->prims[prim_idx], r, EPSILON, max_dist, &t)) return 1;
+            }
+        } else if (stack_ptr < 30) {
+            stack[stack_ptr++] = node->left_child;
+            stack[stack_ptr++] = node->right_child;
+        }
+    }
+    return 0;
+}
+int po_visibility_blocked(const po_scene* sc, const float o[3], const float d[3], float max_dist, int source_idx, int target_idx) {
+    const ray_t r = make_ray(V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
+    return visibility_test_anyhit(sc, &r, max_dist, source_idx, target_idx);
+}
+
+typedef struct { const float* area; const v3* centroid; const v3* radiosity; } solver_geom;
+
+/* form_factors.h:219-366 calculate_form_factors_mc_kernel, one (i, j) pair; adds the pair's partial sums to row i's
+ * grids; returns F_ij */
+static float form_factor_mc_pair(const po_scene* sc, const solver_geom* g, int i, int j, int n_samples,
+                                 float* grid_i, v3* rad_grid_i, uint64_t* rays) {
+    const int num_primitives = sc->n_prims;
+    const int ff_idx = i * num_primitives + j;
+    if (i == j) return 0.0f;
+    const oprim* prim_i = &sc->prims[i]; const oprim* prim_j = &sc->prims[j];
+    const v3 center_i = g->centroid[i], center_j = g->centroid[j];
+    const v3 normal_i = prim_i->normal, normal_j = prim_j->normal;
+    const v3 dir_ij = vsub(center_j, center_i);
+    const float dist_sq = dir_ij.e[0] * dir_ij.e[0] + dir_ij.e[1] * dir_ij.e[1] + dir_ij.e[2] * dir_ij.e[2];
+    const float dist = sqrtf(dist_sq);
+    if (dist < 1e-6f) return 0.0f;
+    const v3 dir_norm = vdivs(dir_ij, dist);
+    const float cos_i_approx = vdot(normal_i, dir_norm);
+    const float cos_j_approx = -vdot(normal_j, dir_norm);
+    if (cos_i_approx <= 0.0f || cos_j_approx <= 0.0f) return 0.0f;
+    const float approx_ff = (float)((double)(cos_i_approx * cos_j_approx * g->area[j]) / (PTMI_PI_D * (double)dist_sq));
+    int actual_samples = n_samples;
+    if (approx_ff < 0.001f) actual_samples = n_samples / 4 > 1 ? n_samples / 4 : 1;
+    else if (approx_ff < 0.01f) actual_samples = n_samples / 2 > 2 ? n_samples / 2 : 2;
+
+    uint32_t local_state[6];
+    po_rng_init(12345u + (uint64_t)(int64_t)ff_idx, (uint64_t)(int64_t)ff_idx, local_state);   /* :85-89 formfactor_rand_init */
+    float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
+    int valid_samples = 0;
+    float local_grid[GRID_SIZE]; v3 local_rad_grid[GRID_SIZE];
+    for (int k = 0; k < GRID_SIZE; k++) { local_grid[k] = 0.0f; local_rad_grid[k] = V(0.0f, 0.0f, 0.0f); }
+    for (int s = 0; s < actual_samples; ++s) {
+        float r1 = rng_uniform(local_state), r2 = rng_uniform(local_state);
+        const v3 p_i = prim_sample_uniform(prim_i, r1, r2);
+        r1 = rng_uniform(local_state); r2 = rng_uniform(local_state);
+        const v3 p_j = prim_sample_uniform(prim_j, r1, r2);
+        v3 sample_dir = vsub(p_j, p_i);
+        const float r = vlen(sample_dir);
+        if (r < 1e-6f) continue;
+        sample_dir = vdivs(sample_dir, r);
+        const float cos_theta_i = vdot(normal_i, sample_dir);
+        const float cos_theta_j = -vdot(normal_j, sample_dir);
+        if (cos_theta_i <= 0.0f || cos_theta_j <= 0.0f) continue;
+        const ray_t shadow_ray = make_ray(vadd(p_i, vscale(1e-4f, normal_i)), sample_dir);
+        (*rays)++;
+        if (!visibility_test_anyhit(sc, &shadow_ray, r - 2e-4f, i, j)) {
+            visibility_sum += 1.0f; cos_i_sum += cos_theta_i; cos_j_sum += cos_theta_j; dist_sum += r;
+            valid_samples++;
+            const int grid_idx = direction_to_grid_index_local(sample_dir, normal_i);
+            local_grid[grid_idx] += 1.0f;
+            const float geometric_weight = (cos_theta_i * cos_theta_j) / (r * r);
+            const v3 contrib = vscale(g->area[j], vscale(geometric_weight, g->radiosity[j]));
+            local_rad_grid[grid_idx] = vadd(local_rad_grid[grid_idx], contrib);
+        }
+    }
+    for (int k = 0; k < GRID_SIZE; k++)
+        if (local_grid[k] > 0.0f) { grid_i[k] += local_grid[k]; rad_grid_i[k] = vadd(rad_grid_i[k], local_rad_grid[k]); }
+    if (valid_samples > 0) {
+        const float avg_cos_i = cos_i_sum / (float)valid_samples;
+        const float avg_cos_j = cos_j_sum / (float)valid_samples;
+        const float avg_dist = dist_sum / (float)valid_samples;
+        const float visibility_fraction = visibility_sum / (float)actual_samples;
+        const float F_ij = (float)((double)(visibility_fraction * (avg_cos_i * avg_cos_j * g->area[j])) /
+                                   (PTMI_PI_D * (double)avg_dist * (double)avg_dist));
+        return fmaxf(0.0f, fminf(F_ij, 1.0f));
+    }
+    return 0.0f;
+}
+
+/* form_factors.h:368-415 calculate_form_factors_kernel (point-to-point) */
+static float form_factor_p2p_pair(const po_scene* sc, const solver_geom* g, int i, int j, uint64_t* rays) {
+    if (i == j) return 0.0f;
+    const v3 vec_ij = vsub(g->centroid[j], g->centroid[i]);
+    const float r = vlen(vec_ij);
+    if (r < 1e-6f) return 0.0f;
+    const v3 dir_ij = vdivs(vec_ij, r);
+    const v3 normal_i = sc->prims[i].normal, normal_j = sc->prims[j].normal;
+    const float cos_theta_i = vdot(normal_i, dir_ij);
+    const float cos_theta_j = vdot(normal_j, vneg(dir_ij));
+    if (cos_theta_i <= 0.0f || cos_theta_j <= 0.0f) return 0.0f;
+    const ray_t visibility_ray = make_ray(vadd(g->centroid[i], vscale(1e-4f, normal_i)), dir_ij);
+    (*rays)++;
+    if (visibility_test_anyhit(sc, &visibility_ray, r - 2e-4f, i, j)) return 0.0f;
+    const float ff = (float)((double)(cos_theta_i * cos_theta_j * g->area[j]) / (PTMI_PI_D * (double)r * (double)r));
+    return fmaxf(0.0f, ff);
+}
+
+/* grid_filter.h:35-41 */
+static float gaussian_weight(float distance, float sigma) { return ptmi_expf(-(distance * distance) / (2.0f * sigma * sigma)); }
+static float luminance_from_rgb(v3 rgb) { return 0.2126f * rgb.e[0] + 0.7152f * rgb.e[1] + 0.0722f * rgb.e[2]; }
+#define BILATERAL_KERNEL_RADIUS 2
+/* grid_filter.h:55-101 bilateralFilterCell / :221-249 gaussianFilterCell */
+static v3 filter_cell(const v3* input_grid, int center_i, int center_j, int bilateral, float sigma_spatial, float sigma_range) {
+    const v3 center_val = input_grid[center_i * GRID_RES + center_j];
+    const float center_lum = luminance_from_rgb(center_val);
+    v3 weighted_sum = V(0.0f, 0.0f, 0.0f);
+    float total_weight = 0.0f;
+    for (int di = -BILATERAL_KERNEL_RADIUS; di <= BILATERAL_KERNEL_RADIUS; di++)
+        for (int dj = -BILATERAL_KERNEL_RADIUS; dj <= BILATERAL_KERNEL_RADIUS; dj++) {
+            const int ni = center_i + di;
+            const int nj = (center_j + dj + GRID_RES) % GRID_RES;           /* phi wraps, theta does not */
+            if (ni < 0 || ni >= GRID_RES) continue;
+            const v3 neighbor_val = input_grid[ni * GRID_RES + nj];
+            const float spatial_dist = sqrtf((float)(di * di + dj * dj));
+            float weight = gaussian_weight(spatial_dist, sigma_spatial);
+            if (bilateral) {
+                const float range_dist = fabsf(center_lum - luminance_from_rgb(neighbor_val));
+                weight = weight * gaussian_weight(range_dist, sigma_range);
+            }
+            weighted_sum = vadd(weighted_sum, vscale(weight, neighbor_val));
+            total_weight += weight;
+        }
+    if (total_weight > 1e-6f) return vdivs(weighted_sum, total_weight);
+    return center_val;
+}
+
+int po_radiosity_solve(po_scene* sc, const po_radiosity_params* prm, int n_threads, float* out_form_factors,
+                       float* out_radiosity, float* out_unshot, float* out_grid, float* out_rad_grid, uint64_t* out_rays) {
+    if (!sc || !prm || sc->n_prims <= 0 || sc->n_prims > 46340 || prm->num_iterations < 0 || prm->mc_samples < 1) return -1;
+    const int n = sc->n_prims;
+    init_jump_tables();
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_num_procs();
+#else
+    n_threads = 1;
+#endif
+    float* area = (float*)malloc(sizeof(float) * (size_t)n);
+    v3* centroid = (v3*)malloc(sizeof(v3) * (size_t)n);
+    v3* radiosity = (v3*)malloc(sizeof(v3) * (size_t)n);
+    v3* unshot = (v3*)malloc(sizeof(v3) * (size_t)n);
+    v3* next_unshot = (v3*)malloc(sizeof(v3) * (size_t)n);
+    float* ff = (float*)malloc(sizeof(float) * (size_t)n * (size_t)n);
+    float* grid = (float*)calloc((size_t)n * GRID_SIZE, sizeof(float));           /* initialize_directional_grids :71-83 */
+    v3* rad_grid = (v3*)calloc((size_t)n * GRID_SIZE, sizeof(v3));
+    for (int i = 0; i < n; i++) {
+        area[i] = prim_area(&sc->prims[i]); centroid[i] = prim_centroid(&sc->prims[i]);
+        radiosity[i] = sc->prims[i].Le; unshot[i] = sc->prims[i].Le;              /* application_state.h:697-701 */
+    }
+    const solver_geom g = { area, centroid, radiosity };
+    uint64_t rays_total = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : rays_total)
+    for (int i = 0; i < n; i++) {
+        uint64_t rays = 0;
+        for (int j = 0; j < n; j++)
+            ff[(size_t)i * n + j] = prm->use_monte_carlo
+                ? form_factor_mc_pair(sc, &g, i, j, prm->mc_samples, grid + (size_t)i * GRID_SIZE, rad_grid + (size_t)i * GRID_SIZE, &rays)
+                : form_factor_p2p_pair(sc, &g, i, j, &rays);
+        rays_total += rays;
+    }
+    for (int it = 0; it < prm->num_iterations; ++it) {
+        /* radiosity_iteration_kernel :441-465 */
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+        for (int i = 0; i < n; i++) {
+            v3 incident_rad = V(0.0f, 0.0f, 0.0f);
+            for (int j = 0; j < n; ++j)
+                if (i != j) {
+                    const float F_ij = ff[(size_t)i * n + j];
+                    if (F_ij > 0.0f) incident_rad = vadd(incident_rad, vscale(F_ij, unshot[j]));
+                }
+            const v3 bsdf = sc->prims[i].bsdf;
+            const v3 reflected = V(fminf(bsdf.e[0] * incident_rad.e[0], incident_rad.e[0]),
+                                   fminf(bsdf.e[1] * incident_rad.e[1], incident_rad.e[1]),
+                                   fminf(bsdf.e[2] * incident_rad.e[2], incident_rad.e[2]));
+            radiosity[i] = vadd(radiosity[i], reflected);
+            next_unshot[i] = reflected;
+        }
+        { v3* t = unshot; unshot = next_unshot; next_unshot = t; }
+        /* update_radiosity_grid :405-439 and the optional filter are recomputed from scratch by every iteration and
+         * feed nothing but the final output: evaluated once, after the last iteration, below */
+    }
+    if (prm->num_iterations > 0) {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+        for (int i = 0; i < n; i++) {
+            v3* rg = rad_grid + (size_t)i * GRID_SIZE;
+            for (int k = 0; k < GRID_SIZE; k++) rg[k] = V(0.0f, 0.0f, 0.0f);
+            for (int j = 0; j < n; ++j) {
+                if (i == j) continue;
+                const float F_ij = ff[(size_t)i * n + j];
+                if (F_ij <= 0.0f) continue;
+                v3 dir_ij = vsub(centroid[j], centroid[i]);
+                const float r = vlen(dir_ij);
+                if (r < 1e-6f) continue;
+                dir_ij = vdivs(dir_ij, r);
+                const int grid_idx = direction_to_grid_index_local(dir_ij, sc->prims[i].normal);
+                rg[grid_idx] = vadd(rg[grid_idx], vscale(F_ij, radiosity[j]));
+            }
+            if (prm->enable_filtering) {                                            /* application_state.h:759-767 */
+                v3 tmp[GRID_SIZE];
+                for (int c = 0; c < GRID_SIZE; c++)
+                    tmp[c] = filter_cell(rg, c / GRID_RES, c % GRID_RES, prm->use_bilateral, prm->filter_sigma_spatial, prm->filter_sigma_range);
+                memcpy(rg, tmp, sizeof tmp);
+            }
+        }
+    }
+    if (out_form_factors) memcpy(out_form_factors, ff, sizeof(float) * (size_t)n * (size_t)n);
+    if (out_radiosity) memcpy(out_radiosity, radiosity, sizeof(v3) * (size_t)n);
+    if (out_unshot) memcpy(out_unshot, unshot, sizeof(v3) * (size_t)n);
+    if (out_grid) memcpy(out_grid, grid, sizeof(float) * (size_t)n * GRID_SIZE);
+    if (out_rad_grid) memcpy(out_rad_grid, rad_grid, sizeof(v3) * (size_t)n * GRID_SIZE);
+    if (out_rays) *out_rays = rays_total;
+    /* ui_windows.h:185-192: runSolver; precomputeCDFs(); upload primitives (radiosity now visible to render_radiosity) */
+    po_scene_set_radiosity(sc, (const float*)radiosity);
+    po_scene_set_radiosity_grids(sc, (const float*)rad_grid);
+    free(area); free(centroid); free(radiosity); free(unshot); free(next_unshot); free(ff); free(grid); free(rad_grid);
+    return 0;
+}
+
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 int po_render(const po_scene* sc, const po_camera* cam, int width, int height, int spp, int max_depth, int sampling_mode,

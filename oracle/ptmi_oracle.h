@@ -56,6 +56,27 @@ void po_scene_get_bvh(const po_scene*, float* bmin, float* bmax, int* left, int*
  * order (NULL removes them); precomputeCDFs (application_state.h:492-585) turns them into the 2120-byte records */
 void po_scene_set_radiosity_grids(po_scene*, const float* rgb);
 void po_scene_set_mis_fraction(po_scene*, float f);
+
+/* radiosity pre-pass: RadiosityState::runSolver (application_state.h:688-777).  Runs the form-factor
+ * kernel (Monte Carlo or point-to-point), num_iterations Jacobi steps, the directional radiosity grids (+ optional
+ * filter), then does what the UI does after the solver (ui_windows.h:185-192): precomputeCDFs and the primitive
+ * upload, i.e. the scene's radiosity and CDF records are replaced.  Outputs (any may be NULL), load order:
+ * form factors n*n, radiosity n*3, unshot n*3, count grid n*256, radiosity grid n*256*3, shadow rays cast. */
+typedef struct {
+    int num_iterations;       /* RadiosityState::num_iterations, 10 (application_state.h:208) */
+    int mc_samples;           /* 64 */
+    int use_monte_carlo;      /* 1 */
+    int enable_filtering;     /* AppConfig::enable_grid_filtering, 0 (application_state.h:290) */
+    int use_bilateral;        /* 1 */
+    float filter_sigma_spatial, filter_sigma_range;   /* 1.5, 0.3 */
+} po_radiosity_params;
+int po_radiosity_solve(po_scene*, const po_radiosity_params*, int n_threads, float* out_form_factors, float* out_radiosity,
+                       float* out_unshot, float* out_grid, float* out_rad_grid, uint64_t* out_rays);
+/* stage hooks for the tests */
+void po_prim_geometry(const po_scene*, int i, float* area, float centroid[3]);
+void po_prim_sample_uniform(const po_scene*, int i, float r1, float r2, float out[3]);
+int po_direction_to_grid_index(const float dir[3], const float normal[3]);
+int po_visibility_blocked(const po_scene*, const float o[3], const float d[3], float max_dist, int source_idx, int target_idx);
 int po_scene_get_cdfs(const po_scene*, float* out /* n_prims * 530 floats */);
 
 /* camera, rng, numerics -------------------------------------------------- */

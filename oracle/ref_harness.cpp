@@ -122,6 +122,12 @@ void ref_centroid(void* h, int i, float* out) {
     Vector3f c = ((RefScene*)h)->prims[i].centroid();
     for (int k = 0; k < 3; k++) out[k] = c[k];
 }
+// radiosity pre-pass helpers that live in primitive.h (:100-102 getArea, :150-191 sampleUniform)
+float ref_area(void* h, int i) { return ((RefScene*)h)->prims[i].getArea(); }
+void ref_sample_uniform(void* h, int i, float r1, float r2, float* out) {
+    Vector3f p = ((RefScene*)h)->prims[i].sampleUniform(r1, r2);
+    for (int k = 0; k < 3; k++) out[k] = p[k];
+}
 void ref_unit_vector(const float* v, float* out) {
     Vector3f u = unit_vector(v3(v));
     for (int k = 0; k < 3; k++) out[k] = u[k];

@@ -40,6 +40,18 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("hits", C.c_uint64)]
 
 
+class RadiosityParams(C.Structure):
+    """RadiosityState / AppConfig defaults (application_state.h:207-209, 290-291)"""
+    _fields_ = [("num_iterations", C.c_int), ("mc_samples", C.c_int), ("use_monte_carlo", C.c_int),
+                ("enable_filtering", C.c_int), ("use_bilateral", C.c_int),
+                ("filter_sigma_spatial", C.c_float), ("filter_sigma_range", C.c_float)]
+
+    def __init__(self, num_iterations=10, mc_samples=64, use_monte_carlo=True, enable_filtering=False, use_bilateral=True,
+                 filter_sigma_spatial=1.5, filter_sigma_range=0.3):
+        super().__init__(num_iterations, mc_samples, int(use_monte_carlo), int(enable_filtering), int(use_bilateral),
+                         filter_sigma_spatial, filter_sigma_range)
+
+
 class Hit(C.Structure):
     _fields_ = [("hit", C.c_int), ("prim", C.c_int), ("t", C.c_float), ("p", C.c_float * 3),
                 ("n", C.c_float * 3), ("bsdf", C.c_float * 3), ("Le", C.c_float * 3),
@@ -100,6 +112,14 @@ def oracle_lib():
         L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.po_radiosity_solve.restype = C.c_int
+        L.po_radiosity_solve.argtypes = [C.c_void_p, C.POINTER(RadiosityParams), C.c_int] + [C.c_void_p] * 6
+        L.po_prim_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+        L.po_prim_sample_uniform.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.po_direction_to_grid_index.restype = C.c_int
+        L.po_direction_to_grid_index.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_visibility_blocked.restype = C.c_int
+        L.po_visibility_blocked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int]
         _oracle = L
     return _oracle
 
@@ -186,6 +206,32 @@ class OracleScene:
             raise RuntimeError(f"po_render_radiosity failed: {rc}")
         return rgb, rad
 
+    def radiosity_solve(self, n_threads=0, **params):
+        """runSolver + precomputeCDFs (ui_windows.h:185-192); returns dict of the solver's outputs (load order)."""
+        n = self.n_prims
+        prm = RadiosityParams(**params)
+        out = dict(form_factors=np.zeros((n, n), np.float32), radiosity=np.zeros((n, 3), np.float32),
+                   unshot=np.zeros((n, 3), np.float32), grid=np.zeros((n, 256), np.float32),
+                   radiosity_grid=np.zeros((n, 256, 3), np.float32))
+        rays = C.c_uint64(0)
+        rc = self.L.po_radiosity_solve(self.h, C.byref(prm), n_threads, out["form_factors"].ctypes.data, out["radiosity"].ctypes.data,
+                                       out["unshot"].ctypes.data, out["grid"].ctypes.data, out["radiosity_grid"].ctypes.data,
+                                       C.addressof(rays))
+        if rc != 0:
+            raise RuntimeError(f"po_radiosity_solve failed: {rc}")
+        out["rays"] = rays.value
+        return out
+
+    def prim_geometry(self, i):
+        a = C.c_float(0); c = np.zeros(3, np.float32)
+        self.L.po_prim_geometry(self.h, i, C.byref(a), c.ctypes.data)
+        return np.float32(a.value), c
+
+    def sample_uniform(self, i, r1, r2):
+        out = np.zeros(3, np.float32)
+        self.L.po_prim_sample_uniform(self.h, i, float(r1), float(r2), out.ctypes.data)
+        return out
+
     def set_mis_fraction(self, f):
         self.L.po_scene_set_mis_fraction(self.h, float(f))
 
@@ -250,6 +296,9 @@ def ref_lib():
         L.ref_quad_geometric_normal.argtypes = [C.c_void_p] * 5
         L.ref_centroid.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ref_unit_vector.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_area.restype = C.c_float
+        L.ref_area.argtypes = [C.c_void_p, C.c_int]
+        L.ref_sample_uniform.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.ref_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                     C.c_int, C.c_void_p]
         _ref = L

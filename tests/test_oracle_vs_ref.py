@@ -179,3 +179,24 @@ def test_large_tessellated_scene_bvh_and_intersect():
             hits += 1
             assert F(oh.t).view(np.uint32) == F(rh[i].t).view(np.uint32)
     assert hits > 300
+
+
+def test_radiosity_prepass_primitive_helpers_bit_exact(pairs):
+    """The pieces of the radiosity pre-pass that live in primitive.h - getArea (as the constructors
+    computed it), centroid, sampleUniform (triangle barycentric / quad split by area ratio) - against the compiled
+    reference.  form_factors.h itself needs <cuda_runtime.h> and is restated only."""
+    L = ref_lib()
+    rng = np.random.default_rng(21)
+    for name, o, r in pairs:
+        n = o.n_prims
+        for i in (range(n) if n <= 64 else rng.integers(0, n, 64)):
+            i = int(i)
+            area, cen = o.prim_geometry(i)
+            assert bits(area) == bits(F(L.ref_area(r.h, i))), (name, i)
+            ref_c = np.zeros(3, F); L.ref_centroid(r.h, i, ref_c.ctypes.data)
+            assert (bits(cen) == bits(ref_c)).all(), (name, i)
+            us = rng.random((12, 2)).astype(F)
+            us[0] = [1.0, 1.0]; us[1] = [2.3283064e-10 / 2, 0.5]; us[2] = [0.5, 1.0]      # curand_uniform's range is (0, 1]
+            for r1, r2 in us:
+                ref_p = np.zeros(3, F); L.ref_sample_uniform(r.h, i, float(r1), float(r2), ref_p.ctypes.data)
+                assert (bits(o.sample_uniform(i, r1, r2)) == bits(ref_p)).all(), (name, i, r1, r2)
