@@ -82,6 +82,7 @@ int ptmi_load_scene(ptmi_ctx* c, const char* filename, int subdivision_count, in
         need(subdivision_count >= 0 && subdivision_count <= 10, "subdivision_count must be in [0, 10]");   // UI range, ui_windows.h:213
         PTMI_HIP(hipSetDevice(c->app.device_id));
         c->app.config.convert_quads_to_triangles = convert_quads != 0;
+        c->app.radiosity.cleanup();                       // a solution belongs to the scene it was computed for
         c->app.scene.loadScene(filename, subdivision_count, convert_quads != 0);
     });
 }
@@ -91,6 +92,7 @@ int ptmi_load_scene_arrays(ptmi_ctx* c, int n, const int* type, const float* ver
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
         PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.radiosity.cleanup();
         c->app.scene.loadSceneArrays(prims_from_arrays(n, type, verts, normal, bsdf, Le));
     });
 }
@@ -226,6 +228,47 @@ int ptmi_set_radiosity(ptmi_ctx* c, int n_prims, const float* rgb) {
         need(rgb == nullptr || n_prims == (int)c->app.scene.h_primitives.size(), "n_prims does not match the loaded scene");
         PTMI_HIP(hipSetDevice(c->app.device_id));
         c->app.scene.setRadiosity(rgb);
+    });
+}
+void ptmi_default_radiosity_params(ptmi_radiosity_params* p) {
+    if (!p) return;
+    p->num_iterations = 10; p->mc_samples = 64; p->use_monte_carlo = 1;
+    p->enable_filtering = 0; p->use_bilateral = 1; p->filter_sigma_spatial = 1.5f; p->filter_sigma_range = 0.3f;
+}
+int ptmi_run_radiosity_solver(ptmi_ctx* c, const ptmi_radiosity_params* p, ptmi_radiosity_stats* stats) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(c->app.scene.d_nodes != nullptr, "no scene loaded");
+        ptmi_radiosity_params prm;
+        if (p) prm = *p; else ptmi_default_radiosity_params(&prm);
+        need(prm.num_iterations >= 0 && prm.num_iterations <= 1000, "num_iterations must be in [0, 1000]");
+        need(prm.mc_samples >= 1 && prm.mc_samples <= 65536, "mc_samples must be in [1, 65536]");
+        need(prm.filter_sigma_spatial > 0.0f && prm.filter_sigma_range > 0.0f, "filter sigmas must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        RadiosityState& r = c->app.radiosity;
+        r.num_iterations = prm.num_iterations; r.mc_samples = prm.mc_samples; r.use_monte_carlo = prm.use_monte_carlo != 0;
+        RadiosityStats st;
+        r.runSolver(c->app.scene, c->app.render.d_jump, prm.enable_filtering != 0, prm.use_bilateral != 0,
+                    prm.filter_sigma_spatial, prm.filter_sigma_range, c->app.render.stream, &st);
+        c->app.scene.precomputeCDFs(r.h_radiosity_grid.data());          // ui_windows.h:189
+        c->app.scene.setRadiosity(r.h_radiosity.data());                 // ui_windows.h:190-191 (primitive upload)
+        if (stats) {
+            stats->seconds = st.seconds; stats->form_factor_ms = st.form_factor_ms; stats->iteration_ms = st.iteration_ms;
+            stats->grid_ms = st.grid_ms; stats->pairs = st.pairs; stats->rays = st.rays;
+        }
+    });
+}
+int ptmi_get_radiosity_solution(const ptmi_ctx* c, float* form_factors, float* radiosity, float* unshot, float* grid, float* radiosity_grid) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        const RadiosityState& r = c->app.radiosity;
+        need(r.is_calculated, "no radiosity solution (run ptmi_run_radiosity_solver first)");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        if (form_factors) r.readFormFactors(form_factors);
+        if (radiosity) std::memcpy(radiosity, r.h_radiosity.data(), r.h_radiosity.size() * sizeof(float));
+        if (unshot) std::memcpy(unshot, r.h_unshot.data(), r.h_unshot.size() * sizeof(float));
+        if (grid) std::memcpy(grid, r.h_grid.data(), r.h_grid.size() * sizeof(float));
+        if (radiosity_grid) std::memcpy(radiosity_grid, r.h_radiosity_grid.data(), r.h_radiosity_grid.size() * sizeof(float));
     });
 }
 int ptmi_get_precomputed_cdfs(const ptmi_ctx* c, float* out) {

@@ -109,6 +109,39 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
 
 size_t bounce_lds_bytes(const DeviceScene& sc);
 
+// ---- radiosity pre-pass (radiosity.hip) ----------------------------------------------------------------
+// Load-order geometry the form-factor kernels sample (the traversal keeps using the leaf-order prims above):
+//   geo[6*p+0] = (v0 | v00, bits(type))      geo[6*p+3] = (-  | v01, 0)
+//   geo[6*p+1] = (v1 | v10, area)            geo[6*p+4] = (normal, 0)
+//   geo[6*p+2] = (v2 | v11, area_ratio)      geo[6*p+5] = (centroid, 0)
+// area / area_ratio / centroid are computed on the host with the float expressions of triangle.h:28, quad.h:31 and
+// primitive.h:92-98, 161-170 (pure functions of the vertices).
+constexpr int kGridRes = 16, kGridSize = 256;
+struct RadiosityBuffers {
+    const float4* geo = nullptr;
+    const int* slot_of = nullptr;      // load-order index -> leaf-order slot (to skip source/target in the visibility test)
+    const float4* bsdf = nullptr;      // (bsdf.xyz, 0), load order
+    float4* radiosity = nullptr;       // (rgb, 0), load order
+    float4* unshot[2] = {nullptr, nullptr};   // Jacobi double buffer
+    float* form_factors = nullptr;     // n * n, row i = receiver
+    unsigned int* grid = nullptr;      // n * 256 visible-sample counts (Triangle/Quad::grid; integers, so exact in any order)
+    float4* rad_grid = nullptr;        // n * 256 (rgb, 0)  (Triangle/Quad::radiosity_grid)
+    unsigned long long* rays = nullptr;   // shadow rays cast (1 counter)
+    int n = 0;
+    int bvh_depth = 0;                 // > 30: the visibility walk keeps the reference's explicit stack and drop rule
+};
+struct RadiosityParams {
+    int num_iterations, mc_samples, use_monte_carlo, enable_filtering, use_bilateral;
+    float filter_sigma_spatial, filter_sigma_range;
+};
+// calculate_form_factors_mc_kernel / calculate_form_factors_kernel (form_factors.h:219-415) incl. formfactor_rand_init
+// (:85-89, fused: a pair's XORWOW stream is derived where it is used) and initialize_directional_grids (:71-83)
+void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, const RadiosityParams& prm, const uint32_t* d_jump, hipStream_t s);
+// radiosity_iteration_kernel (form_factors.h:441-465), Jacobi: reads unshot[src], writes unshot[1 - src]
+void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s);
+// update_radiosity_grid (form_factors.h:405-439) + the optional filter (grid_filter.h:103-165, 251-312)
+void launch_radiosity_grid(const RadiosityBuffers& rb, const RadiosityParams& prm, hipStream_t s);
+
 // test hooks
 void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
                             int* hit, int* prim, float* t, float* p, float* nrm, hipStream_t s);

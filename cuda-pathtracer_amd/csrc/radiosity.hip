@@ -1,0 +1,468 @@
+// radiosity.hip — gfx950 kernels of the radiosity pre-pass: RadiosityState::runSolver
+// (application_state.h:688-777) and its kernels (form_factors.h:71-467, grid_filter.h:35-312).
+//
+// Compile with -ffp-contract=off (see include/ptmi_math.h, pt_vec.h): every output except the num_iterations == 0
+// radiosity grid (order-dependent float atomics in the reference itself) is bit-identical to oracle/ptmi_oracle.c.
+//
+// Kernels
+//   ptmi_form_factors       one WORKGROUP per receiver i (the reference: one thread per (i, j) pair).  The workgroup owns
+//                           row i of the form-factor matrix and primitive i's two directional grids, so the reference's
+//                           global atomics become LDS adds and one plain store per cell.  Pairs are culled first
+//                           (form_factors.h:234-256: ~2/3 of all pairs in a closed scene) and the survivors compacted
+//                           through an LDS queue, so the Monte-Carlo loop runs on dense waves.  The reference keeps n^2
+//                           curandStates (48 B each) that nothing reads after the kernel; here a pair's XORWOW stream
+//                           is derived where it is used, for surviving pairs only.
+//   ptmi_radiosity_iterate  radiosity_iteration_kernel (form_factors.h:441-465) with the race removed (Jacobi)
+//   ptmi_radiosity_grid     update_radiosity_grid (form_factors.h:405-439) + the optional 5x5 filter (grid_filter.h);
+//                           one workgroup per primitive, one thread per grid cell, contributions added in ascending j
+#include "pt_device.h"
+
+namespace ptmi {
+
+namespace {
+
+constexpr int kQueueCap = 2 * kBlock;
+
+struct Geom { f3 v0, v1, v2, v3; int type; float area, ratio; f3 normal, centroid; };
+
+__device__ __forceinline__ Geom load_geom(const float4* __restrict__ geo, int p) {
+    const float4 a = geo[6 * p], b = geo[6 * p + 1], c = geo[6 * p + 2], d = geo[6 * p + 3], e = geo[6 * p + 4], f = geo[6 * p + 5];
+    Geom g;
+    g.v0 = xyz(a); g.v1 = xyz(b); g.v2 = xyz(c); g.v3 = xyz(d);
+    g.type = __float_as_int(a.w); g.area = b.w; g.ratio = c.w;
+    g.normal = xyz(e); g.centroid = xyz(f);
+    return g;
+}
+
+// primitive.h:153-157
+__device__ __forceinline__ f3 bary_point(f3 a, f3 b, f3 c, float r1, float r2) {
+    const float sqrt_r1 = sqrt_rn(r1);
+    const float u = 1.0f - sqrt_r1;
+    const float v = sqrt_r1 * (1.0f - r2);
+    const float w = sqrt_r1 * r2;
+    return u * a + v * b + w * c;
+}
+// Primitive::sampleUniform (primitive.h:150-191); the quad's area ratio comes precomputed from the host
+__device__ __forceinline__ f3 sample_uniform(const Geom& g, float r1, float r2) {
+    if (g.type == 0) return bary_point(g.v0, g.v1, g.v2, r1, r2);
+    if (r1 < g.ratio) return bary_point(g.v0, g.v1, g.v3, r1 / g.ratio, r2);                     // (v00, v10, v01)
+    return bary_point(g.v1, g.v2, g.v3, (r1 - g.ratio) / (1.0f - g.ratio), r2);                  // (v10, v11, v01)
+}
+
+// direction_to_grid_indices_local (form_factors.h:107-130): theta over [0, pi] -> 16 rows, phi over [0, 2 pi) -> 16 columns
+__device__ __forceinline__ int direction_to_grid_index_local(f3 world_dir, f3 normal) {
+    f3 tangent, bitangent;
+    build_frame(normal, tangent, bitangent);
+    const float lx = dot(world_dir, tangent), ly = dot(world_dir, bitangent), lz = dot(world_dir, normal);
+    const float r = sqrt_rn(lx * lx + ly * ly + lz * lz);
+    const float theta = (r > 0.0f) ? ptmi_acosf(fminf(lz / r, 1.0f)) : 0.0f;
+    float phi = ptmi_atan2f(ly, lx);
+    if (phi < 0.0f) phi = (float)((double)phi + (double)2.0f * PTMI_PI_D);
+    int grid_theta = (int)fminf((float)(((double)theta / PTMI_PI_D) * kGridRes), (float)(kGridRes - 1));
+    int grid_phi = (int)fminf((float)(((double)phi / ((double)2.0f * PTMI_PI_D)) * kGridRes), (float)(kGridRes - 1));
+    grid_theta = max(0, min(grid_theta, kGridRes - 1));
+    grid_phi = max(0, min(grid_phi, kGridRes - 1));
+    return grid_theta * kGridRes + grid_phi;
+}
+
+// Primitive::intersect(r, 1e-5f, max_dist) as a yes/no question: triangle.h:82 accepts t <= t_max, quad.h:78,110
+// only t < t_max (closest_t starts at t_max)
+template <bool HAS_QUADS>
+__device__ __forceinline__ bool anyhit_prim(const float4* __restrict__ prims, int prim_stride, int k, f3 o, f3 d, float max_dist) {
+    const float4 p0 = prims[k * prim_stride], p1 = prims[k * prim_stride + 1], p2 = prims[k * prim_stride + 2];
+    const float eps = 1e-8f, eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+    const float t_lo = 1e-5f;                                      // t > 1e-8f && t >= 1e-5f
+    if (HAS_QUADS && __float_as_int(p0.w) != 0) {
+        const float4 p3 = prims[k * prim_stride + 3];
+        const float t1 = mt_candidate(xyz(p0), xyz(p1), xyz(p2), o, d, eps_up, t_lo);
+        const float t2 = mt_candidate(xyz(p0), xyz(p2), xyz(p3), o, d, eps_up, t_lo);
+        return min_raw(t1, t2) < max_dist;
+    }
+    const f3 v0 = xyz(p0), edge1 = xyz(p1), edge2 = xyz(p2);
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = rcp_exact_normal(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const float m1 = min3_raw(fabsf(a) - eps, u, 1.0f - u);
+    if (!__any(m1 >= 0.0f)) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(edge2, q);
+    float m = min3_raw(m1, v, 1.0f - (u + v));
+    m = min_raw(m, t - t_lo);
+    return (m >= 0.0f) & (t <= max_dist);
+}
+
+// slab test of visibility_test_anyhit (form_factors.h:162-180); true = the reference does NOT `continue`
+__device__ __forceinline__ bool anyhit_box(const float4& n0, const float4& n1, f3 o, f3 inv, float max_dist) {
+    const float EPSILON = 1e-5f;
+    float t1 = (n0.x - o.x) * inv.x, t2 = (n1.x - o.x) * inv.x;
+    float tmin = min_raw(t1, t2), tmax = max_raw(t1, t2);
+    t1 = (n0.y - o.y) * inv.y; t2 = (n1.y - o.y) * inv.y;
+    tmin = max_raw(tmin, min_raw(t1, t2)); tmax = min_raw(tmax, max_raw(t1, t2));
+    t1 = (n0.z - o.z) * inv.z; t2 = (n1.z - o.z) * inv.z;
+    tmin = max_raw(tmin, min_raw(t1, t2)); tmax = min_raw(tmax, max_raw(t1, t2));
+    return !(tmax < EPSILON || tmin > max_dist || tmin > tmax);
+}
+
+// visibility_test_anyhit (form_factors.h:143-208).  The answer - is ANY primitive other than source/target hit within
+// max_dist - does not depend on the visiting order unless children get dropped (stack_ptr >= 30), which needs a tree
+// deeper than 31 levels.  DEEP = false: stackless pre-order walk (skip pointers).  DEEP = true: the reference's walk
+// itself - 32-entry stack, left pushed first (so the right child is visited first), children dropped from 30 on.
+template <bool HAS_QUADS, bool DEEP>
+__device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, f3 d, float max_dist, int slot_a, int slot_b) {
+    const f3 inv = mk3(1.0f / (fabsf(d.x) > 1e-8f ? d.x : 1e-8f), 1.0f / (fabsf(d.y) > 1e-8f ? d.y : 1e-8f),
+                       1.0f / (fabsf(d.z) > 1e-8f ? d.z : 1e-8f));
+    const float4* __restrict__ nodes = sc.nodes;
+    if (!DEEP) {
+        int cur = 0;
+        while (cur < sc.n_nodes) {
+            const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+            const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+            const bool pass = anyhit_box(n0, n1, o, inv, max_dist);
+            int next = cur + 1;
+            if (!pass && b >= 0) next = a;
+            if (pass && b < 0) {
+                for (int i = 0; i < -b; i++) {
+                    const int k = a + i;
+                    if (k == slot_a || k == slot_b) continue;
+                    if (anyhit_prim<HAS_QUADS>(sc.prims, sc.prim_stride, k, o, d, max_dist)) return true;
+                }
+            }
+            cur = next;
+        }
+        return false;
+    } else {
+        int stack[32];
+        int sp = 0;
+        stack[sp++] = 0;
+        while (sp > 0) {
+            const int cur = stack[--sp];
+            const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+            if (!anyhit_box(n0, n1, o, inv, max_dist)) continue;
+            const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+            if (b < 0) {
+                for (int i = 0; i < -b; i++) {
+                    const int k = a + i;
+                    if (k == slot_a || k == slot_b) continue;
+                    if (anyhit_prim<HAS_QUADS>(sc.prims, sc.prim_stride, k, o, d, max_dist)) return true;
+                }
+            } else if (sp < 30) {
+                stack[sp++] = cur + 1;      // left child (pre-order numbering)
+                stack[sp++] = b;            // right child: popped first
+            }
+        }
+        return false;
+    }
+}
+
+// formfactor_rand_init (form_factors.h:85-89): curand_init(12345 + idx, idx, 0).  Block-synchronous: one 160x160 GF(2)
+// matrix T^(2^67 * 2^k) at a time is staged in LDS and applied by the threads whose idx has bit k set.
+__device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __restrict__ jump, bool have, unsigned int idx, Rng& out) {
+    const unsigned long long seed = 12345ull + (unsigned long long)idx;
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    const uint32_t d = 6615241u + t1 + t0;
+    for (int k = 0; k < 32; k++) {
+        const bool mine = have && ((idx >> k) & 1u);
+        if (!__syncthreads_or(mine ? 1 : 0)) continue;
+        for (int i = threadIdx.x; i < 160 * 5; i += kBlock) M[i] = jump[k * 160 * 5 + i];
+        __syncthreads();
+        if (mine) {
+            uint32_t r[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int w = 0; w < 5; w++) {
+                const uint32_t word = v[w];
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t m = 0u - ((word >> b) & 1u);
+                    const uint32_t* row = &M[(w * 32 + b) * 5];
+                    r[0] ^= row[0] & m; r[1] ^= row[1] & m; r[2] ^= row[2] & m; r[3] ^= row[3] & m; r[4] ^= row[4] & m;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 5; w++) v[w] = r[w];
+        }
+        __syncthreads();
+    }
+    out = Rng{v[0], v[1], v[2], v[3], v[4], d};
+}
+
+// the sample loop and F_ij of calculate_form_factors_mc_kernel (form_factors.h:259-365) for one surviving pair
+template <bool HAS_QUADS, bool DEEP, bool RAD0>
+__device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, const Geom& gj, int slot_i, int slot_j, int actual_samples,
+                                         Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays) {
+    float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
+    int valid_samples = 0;
+    for (int s = 0; s < actual_samples; ++s) {
+        float r1 = rng_uniform(rng), r2 = rng_uniform(rng);
+        const f3 p_i = sample_uniform(gi, r1, r2);
+        r1 = rng_uniform(rng); r2 = rng_uniform(rng);
+        const f3 p_j = sample_uniform(gj, r1, r2);
+        f3 sample_dir = p_j - p_i;
+        const float r = length(sample_dir);
+        if (r < 1e-6f) continue;
+        sample_dir = div_scalar(sample_dir, r);
+        const float cos_theta_i = dot(gi.normal, sample_dir);
+        const float cos_theta_j = -dot(gj.normal, sample_dir);
+        if (cos_theta_i <= 0.0f || cos_theta_j <= 0.0f) continue;
+        const f3 ro = p_i + 1e-4f * gi.normal;
+        const f3 rd = unit_vector(sample_dir);                                  // Ray's constructor normalises again (ray.h:9-12)
+        rays++;
+        if (!visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) {
+            visibility_sum += 1.0f; cos_i_sum += cos_theta_i; cos_j_sum += cos_theta_j; dist_sum += r;
+            valid_samples++;
+            const int grid_idx = direction_to_grid_index_local(sample_dir, gi.normal);
+            atomicAdd(&counts[grid_idx], 1u);
+            if (RAD0) {
+                const float geometric_weight = (cos_theta_i * cos_theta_j) / (r * r);
+                const f3 contrib = gj.area * (geometric_weight * radiosity_j);
+                atomicAdd(&radg[3 * grid_idx], contrib.x); atomicAdd(&radg[3 * grid_idx + 1], contrib.y); atomicAdd(&radg[3 * grid_idx + 2], contrib.z);
+            }
+        }
+    }
+    if (valid_samples > 0) {
+        const float avg_cos_i = cos_i_sum / (float)valid_samples;
+        const float avg_cos_j = cos_j_sum / (float)valid_samples;
+        const float avg_dist = dist_sum / (float)valid_samples;
+        const float visibility_fraction = visibility_sum / (float)actual_samples;
+        const float F_ij = (float)((double)(visibility_fraction * (avg_cos_i * avg_cos_j * gj.area)) /
+                                   (PTMI_PI_D * (double)avg_dist * (double)avg_dist));
+        return fmaxf(0.0f, fminf(F_ij, 1.0f));
+    }
+    return 0.0f;
+}
+
+// calculate_form_factors_kernel (form_factors.h:368-415) after its culling tests
+template <bool HAS_QUADS, bool DEEP>
+__device__ __forceinline__ float p2p_pair(const DeviceScene& sc, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays) {
+    const f3 vec_ij = gj.centroid - gi.centroid;
+    const float r = length(vec_ij);
+    const f3 dir_ij = div_scalar(vec_ij, r);
+    const float cos_theta_i = dot(gi.normal, dir_ij);
+    const float cos_theta_j = dot(gj.normal, -dir_ij);
+    const f3 ro = gi.centroid + 1e-4f * gi.normal;
+    const f3 rd = unit_vector(dir_ij);
+    rays++;
+    if (visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
+    const float ff = (float)((double)(cos_theta_i * cos_theta_j * gj.area) / (PTMI_PI_D * (double)r * (double)r));
+    return fmaxf(0.0f, ff);
+}
+
+template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0>
+__global__ __launch_bounds__(kBlock) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
+                                                            const uint32_t* __restrict__ jump) {
+    __shared__ uint32_t M[160 * 5];
+    __shared__ unsigned int counts[kGridSize];
+    __shared__ float radg[RAD0 ? 3 * kGridSize : 1];
+    __shared__ int2 queue[kQueueCap];
+    __shared__ int q_n;
+    __shared__ unsigned int rays_wg;
+    const int n = rb.n;
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const Geom gi = load_geom(rb.geo, i);
+    const int slot_i = rb.slot_of[i];
+    float* __restrict__ row = rb.form_factors + (size_t)i * (size_t)n;
+    counts[tid] = 0u;
+    if (RAD0) { radg[3 * tid] = 0.0f; radg[3 * tid + 1] = 0.0f; radg[3 * tid + 2] = 0.0f; }
+    if (tid == 0) { q_n = 0; rays_wg = 0u; }
+    __syncthreads();
+    unsigned int rays = 0u;
+
+    for (int base = 0; base < n; base += kBlock) {
+        const int j = base + tid;
+        int samples = 0;                                    // 0: this pair's form factor is already decided (0)
+        if (j < n) {
+            if (j != i) {
+                const float4 cj = rb.geo[6 * j + 5], nj = rb.geo[6 * j + 4];
+                if (MC) {                                   // form_factors.h:234-256
+                    const f3 dir_ij = xyz(cj) - gi.centroid;
+                    const float dist_sq = dir_ij.x * dir_ij.x + dir_ij.y * dir_ij.y + dir_ij.z * dir_ij.z;
+                    const float dist = sqrt_rn(dist_sq);
+                    if (!(dist < 1e-6f)) {
+                        const f3 dir_norm = div_scalar(dir_ij, dist);
+                        const float cos_i_approx = dot(gi.normal, dir_norm);
+                        const float cos_j_approx = -dot(xyz(nj), dir_norm);
+                        if (!(cos_i_approx <= 0.0f || cos_j_approx <= 0.0f)) {
+                            const float area_j = rb.geo[6 * j + 1].w;
+                            const float approx_ff = (float)((double)(cos_i_approx * cos_j_approx * area_j) / (PTMI_PI_D * (double)dist_sq));
+                            samples = n_samples;
+                            if (approx_ff < 0.001f) samples = max(1, n_samples / 4);
+                            else if (approx_ff < 0.01f) samples = max(2, n_samples / 2);
+                        }
+                    }
+                } else {                                    // form_factors.h:385-401
+                    const f3 vec_ij = xyz(cj) - gi.centroid;
+                    const float r = length(vec_ij);
+                    if (!(r < 1e-6f)) {
+                        const f3 dir_ij = div_scalar(vec_ij, r);
+                        const float cos_theta_i = dot(gi.normal, dir_ij);
+                        const float cos_theta_j = dot(xyz(nj), -dir_ij);
+                        if (!(cos_theta_i <= 0.0f || cos_theta_j <= 0.0f)) samples = 1;
+                    }
+                }
+            }
+            if (samples == 0) row[j] = 0.0f;
+        }
+        if (samples) { const int pos = atomicAdd(&q_n, 1); queue[pos] = make_int2(j, samples); }
+        __syncthreads();
+        const bool last = base + kBlock >= n;
+        while (q_n >= kBlock || (last && q_n > 0)) {        // q_n is block-uniform between barriers
+            const int total = q_n;
+            const int take = min(total, kBlock);
+            const bool have = tid < take;
+            const int2 e = have ? queue[total - take + tid] : make_int2(0, 0);
+            __syncthreads();
+            if (tid == 0) q_n = total - take;
+            Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
+            if (MC) pair_rng_init(M, jump, have, (unsigned int)(i * n + e.x), rng);
+            if (have) {
+                const Geom gj = load_geom(rb.geo, e.x);
+                const int slot_j = rb.slot_of[e.x];
+                float F;
+                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0>(sc, gi, gj, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
+                else F = p2p_pair<HAS_QUADS, DEEP>(sc, gi, gj, slot_i, slot_j, rays);
+                row[e.x] = F;
+            }
+            __syncthreads();
+        }
+    }
+    atomicAdd(&rays_wg, rays);
+    __syncthreads();
+    rb.grid[(size_t)i * kGridSize + tid] = counts[tid];     // initialize_directional_grids + the kernel's atomics, in one store
+    rb.rad_grid[(size_t)i * kGridSize + tid] = RAD0 ? make_float4(radg[3 * tid], radg[3 * tid + 1], radg[3 * tid + 2], 0.0f)
+                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tid == 0 && rb.rays) atomicAdd(rb.rays, (unsigned long long)rays_wg);
+}
+
+// radiosity_iteration_kernel (form_factors.h:441-465): one thread per receiver, ascending j
+__global__ __launch_bounds__(kBlock) void ptmi_radiosity_iterate(RadiosityBuffers rb, int src) {
+    const int n = rb.n;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* __restrict__ row = rb.form_factors + (size_t)i * (size_t)n;
+    const float4* __restrict__ unshot = rb.unshot[src];
+    f3 incident_rad = mk3(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < n; ++j) {
+        if (i != j) {
+            const float F_ij = row[j];
+            if (F_ij > 0.0f) incident_rad = incident_rad + F_ij * xyz(unshot[j]);
+        }
+    }
+    const f3 bsdf = xyz(rb.bsdf[i]);
+    const f3 reflected = mk3(fminf(bsdf.x * incident_rad.x, incident_rad.x), fminf(bsdf.y * incident_rad.y, incident_rad.y),
+                             fminf(bsdf.z * incident_rad.z, incident_rad.z));
+    const f3 rad = xyz(rb.radiosity[i]) + reflected;
+    rb.radiosity[i] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+    rb.unshot[1 - src][i] = make_float4(reflected.x, reflected.y, reflected.z, 0.0f);
+}
+
+// grid_filter.h:35-41, 55-101 (bilateral), 221-249 (gaussian)
+__device__ __forceinline__ float gaussian_weight(float distance, float sigma) { return ptmi_expf(-(distance * distance) / (2.0f * sigma * sigma)); }
+__device__ __forceinline__ float luminance_from_rgb(f3 rgb) { return 0.2126f * rgb.x + 0.7152f * rgb.y + 0.0722f * rgb.z; }
+__device__ __forceinline__ f3 filter_cell(const float4* g, int center_i, int center_j, bool bilateral, float sigma_spatial, float sigma_range) {
+    const f3 center_val = xyz(g[center_i * kGridRes + center_j]);
+    const float center_lum = luminance_from_rgb(center_val);
+    f3 weighted_sum = mk3(0.0f, 0.0f, 0.0f);
+    float total_weight = 0.0f;
+    for (int di = -2; di <= 2; di++)
+        for (int dj = -2; dj <= 2; dj++) {
+            const int ni = center_i + di;
+            const int nj = (center_j + dj + kGridRes) % kGridRes;
+            if (ni < 0 || ni >= kGridRes) continue;
+            const f3 neighbor_val = xyz(g[ni * kGridRes + nj]);
+            const float spatial_dist = sqrt_rn((float)(di * di + dj * dj));
+            float weight = gaussian_weight(spatial_dist, sigma_spatial);
+            if (bilateral) {
+                const float range_dist = fabsf(center_lum - luminance_from_rgb(neighbor_val));
+                weight = weight * gaussian_weight(range_dist, sigma_range);
+            }
+            weighted_sum = weighted_sum + weight * neighbor_val;
+            total_weight += weight;
+        }
+    if (total_weight > 1e-6f) return div_scalar(weighted_sum, total_weight);
+    return center_val;
+}
+
+// update_radiosity_grid (form_factors.h:405-439): workgroup = primitive i, thread = grid cell.  Phase A computes, in
+// parallel, which cell each j falls into (the acos/atan2 part); phase B lets every cell's owner add its contributions
+// in ascending j, the order of the reference's single thread per primitive.
+constexpr int kGridChunk = 2048;
+__global__ __launch_bounds__(kBlock) void ptmi_radiosity_grid(RadiosityBuffers rb, RadiosityParams prm) {
+    __shared__ unsigned short cell[kGridChunk];
+    __shared__ float4 g[kGridSize];
+    const int n = rb.n;
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const f3 center_i = xyz(rb.geo[6 * i + 5]), normal_i = xyz(rb.geo[6 * i + 4]);
+    const float* __restrict__ row = rb.form_factors + (size_t)i * (size_t)n;
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    for (int base = 0; base < n; base += kGridChunk) {
+        const int m = min(kGridChunk, n - base);
+        for (int jj = tid; jj < m; jj += kBlock) {
+            const int j = base + jj;
+            unsigned short c = 0xffffu;
+            if (j != i && row[j] > 0.0f) {
+                f3 dir_ij = xyz(rb.geo[6 * j + 5]) - center_i;
+                const float r = length(dir_ij);
+                if (!(r < 1e-6f)) {
+                    dir_ij = div_scalar(dir_ij, r);
+                    c = (unsigned short)direction_to_grid_index_local(dir_ij, normal_i);
+                }
+            }
+            cell[jj] = c;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < m; jj++) {
+            if (cell[jj] == tid) {
+                const int j = base + jj;
+                acc = acc + row[j] * xyz(rb.radiosity[j]);
+            }
+        }
+        __syncthreads();
+    }
+    if (prm.enable_filtering) {                              // application_state.h:759-767
+        g[tid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        __syncthreads();
+        acc = filter_cell(g, tid / kGridRes, tid % kGridRes, prm.use_bilateral != 0, prm.filter_sigma_spatial, prm.filter_sigma_range);
+    }
+    rb.rad_grid[(size_t)i * kGridSize + tid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+}
+
+template <bool MC, bool Q_, bool D_>
+void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
+    if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+    else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+}
+template <bool MC>
+void launch_ff1(bool quads, bool deep, bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples,
+                const uint32_t* jump) {
+    if (quads) { if (deep) launch_ff3<MC, true, true>(rad0, grid, s, sc, rb, n_samples, jump); else launch_ff3<MC, true, false>(rad0, grid, s, sc, rb, n_samples, jump); }
+    else { if (deep) launch_ff3<MC, false, true>(rad0, grid, s, sc, rb, n_samples, jump); else launch_ff3<MC, false, false>(rad0, grid, s, sc, rb, n_samples, jump); }
+}
+
+}  // namespace
+
+void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, const RadiosityParams& prm, const uint32_t* d_jump, hipStream_t s) {
+    if (rb.n <= 0) return;
+    const dim3 grid(rb.n);
+    const bool deep = rb.bvh_depth > 30, rad0 = prm.num_iterations == 0;
+    if (prm.use_monte_carlo) launch_ff1<true>(sc.has_quads != 0, deep, rad0, grid, s, sc, rb, prm.mc_samples, d_jump);
+    else launch_ff1<false>(sc.has_quads != 0, deep, rad0, grid, s, sc, rb, 0, d_jump);
+}
+
+void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s) {
+    if (rb.n <= 0) return;
+    hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rb, src);
+}
+
+void launch_radiosity_grid(const RadiosityBuffers& rb, const RadiosityParams& prm, hipStream_t s) {
+    if (rb.n <= 0) return;
+    hipLaunchKernelGGL(ptmi_radiosity_grid, dim3(rb.n), dim3(kBlock), 0, s, rb, prm);
+}
+
+}  // namespace ptmi

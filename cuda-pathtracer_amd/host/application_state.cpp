@@ -209,6 +209,114 @@ void SceneState::setRadiosity(const float* rgb) {
     d_scene.radiosity = d_radiosity;
 }
 
+// ---------------------------------------------------------------------------------------------
+// RadiosityState (application_state.h:688-787)
+// ---------------------------------------------------------------------------------------------
+void RadiosityState::cleanup() {
+    void* ptrs[] = {(void*)d.geo, (void*)d.slot_of, (void*)d.bsdf, d.radiosity, d.unshot[0], d.unshot[1], d.form_factors, d.grid, d.rad_grid, d.rays};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d = RadiosityBuffers();
+    is_calculated = false;
+}
+
+void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
+                               float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats) {
+    if (!scene.d_nodes) throw ArgError("runSolver: no scene loaded");
+    const int n = (int)scene.h_primitives.size();
+    if (n > 46340) throw ArgError("runSolver: more than 46340 primitives (the pair index i * n + j is an int in the reference too)");
+    if (num_iterations < 0 || num_iterations > 1000) throw ArgError("runSolver: num_iterations out of range");
+    if (mc_samples < 1 || mc_samples > 65536) throw ArgError("runSolver: mc_samples out of range");
+    cleanup();                                                                       // :703
+    // for (i) setRadiosity(Le), setUnshotRad(Le)  (:697-701) + the load-order geometry the kernels sample
+    std::vector<float4> geo((size_t)n * 6), bsdf((size_t)n), rad((size_t)n);
+    std::vector<int> slot_of((size_t)n);
+    for (int k = 0; k < n; k++) slot_of[scene.bvh_indices[k]] = k;
+    for (int p = 0; p < n; p++) {
+        const Primitive& pr = scene.h_primitives[p];
+        const f3 c = pr.centroid();
+        int type = (int)pr.type; float type_bits; std::memcpy(&type_bits, &type, 4);
+        geo[6 * p + 0] = make_float4(pr.v[0].x, pr.v[0].y, pr.v[0].z, type_bits);
+        geo[6 * p + 1] = make_float4(pr.v[1].x, pr.v[1].y, pr.v[1].z, pr.area());
+        geo[6 * p + 2] = make_float4(pr.v[2].x, pr.v[2].y, pr.v[2].z, pr.sampleAreaRatio());
+        geo[6 * p + 3] = make_float4(pr.v[3].x, pr.v[3].y, pr.v[3].z, 0.0f);
+        geo[6 * p + 4] = make_float4(pr.normal.x, pr.normal.y, pr.normal.z, 0.0f);
+        geo[6 * p + 5] = make_float4(c.x, c.y, c.z, 0.0f);
+        bsdf[p] = make_float4(pr.bsdf.x, pr.bsdf.y, pr.bsdf.z, 0.0f);
+        rad[p] = make_float4(pr.Le.x, pr.Le.y, pr.Le.z, 0.0f);
+    }
+    auto upload = [&](const void* src, size_t bytes, const char* name) {
+        void* p = hipMallocSafe(bytes, name);
+        if (src) PTMI_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return p;
+    };
+    d.n = n; d.bvh_depth = scene.bvh_depth;
+    d.geo = (const float4*)upload(geo.data(), geo.size() * sizeof(float4), "d_radiosity_geo");
+    d.slot_of = (const int*)upload(slot_of.data(), slot_of.size() * sizeof(int), "d_radiosity_slot_of");
+    d.bsdf = (const float4*)upload(bsdf.data(), bsdf.size() * sizeof(float4), "d_radiosity_bsdf");
+    d.radiosity = (float4*)upload(rad.data(), rad.size() * sizeof(float4), "d_radiosity_primitives");
+    d.unshot[0] = (float4*)upload(rad.data(), rad.size() * sizeof(float4), "d_radiosity_unshot0");
+    d.unshot[1] = (float4*)upload(nullptr, rad.size() * sizeof(float4), "d_radiosity_unshot1");
+    d.form_factors = (float*)upload(nullptr, (size_t)n * (size_t)n * sizeof(float), "d_form_factors");
+    d.grid = (unsigned int*)upload(nullptr, (size_t)n * kGridSize * sizeof(unsigned int), "d_radiosity_grid_counts");
+    d.rad_grid = (float4*)upload(nullptr, (size_t)n * kGridSize * sizeof(float4), "d_radiosity_grids");
+    d.rays = (unsigned long long*)upload(nullptr, sizeof(unsigned long long), "d_radiosity_rays");
+    PTMI_HIP(hipMemset(d.rays, 0, sizeof(unsigned long long)));
+
+    RadiosityParams prm;
+    prm.num_iterations = num_iterations; prm.mc_samples = mc_samples; prm.use_monte_carlo = use_monte_carlo ? 1 : 0;
+    prm.enable_filtering = enable_filtering ? 1 : 0; prm.use_bilateral = use_bilateral ? 1 : 0;
+    prm.filter_sigma_spatial = filter_sigma_spatial; prm.filter_sigma_range = filter_sigma_range;
+
+    hipEvent_t ev[4];
+    for (auto& e : ev) PTMI_HIP(hipEventCreate(&e));
+    PTMI_HIP(hipEventRecord(ev[0], stream));
+    launch_form_factors(scene.d_scene, d, prm, d_jump, stream);                       // :726-741
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipEventRecord(ev[1], stream));
+    for (int it = 0; it < num_iterations; ++it) launch_radiosity_iteration(d, it & 1, stream);   // :748-771
+    final_unshot = num_iterations & 1;
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipEventRecord(ev[2], stream));
+    if (num_iterations > 0) launch_radiosity_grid(d, prm, stream);
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipEventRecord(ev[3], stream));
+    PTMI_HIP(hipStreamSynchronize(stream));
+
+    // cudaMemcpy(h_primitives, d_radiosity_primitives, ...) (:773): the solution comes back to the host
+    std::vector<float4> h4((size_t)n * kGridSize);
+    auto unpack = [&](const float4* dev, size_t count, std::vector<float>& out) {
+        PTMI_HIP(hipMemcpy(h4.data(), dev, count * sizeof(float4), hipMemcpyDeviceToHost));
+        out.resize(count * 3);
+        for (size_t k = 0; k < count; k++) { out[3 * k] = h4[k].x; out[3 * k + 1] = h4[k].y; out[3 * k + 2] = h4[k].z; }
+    };
+    unpack(d.radiosity, (size_t)n, h_radiosity);
+    unpack(d.unshot[final_unshot], (size_t)n, h_unshot);
+    unpack(d.rad_grid, (size_t)n * kGridSize, h_radiosity_grid);
+    std::vector<unsigned int> counts((size_t)n * kGridSize);
+    PTMI_HIP(hipMemcpy(counts.data(), d.grid, counts.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    h_grid.resize(counts.size());
+    for (size_t k = 0; k < counts.size(); k++) h_grid[k] = (float)counts[k];
+    is_calculated = true;
+    if (stats) {
+        float ms = 0.0f;
+        *stats = RadiosityStats();
+        PTMI_HIP(hipEventElapsedTime(&ms, ev[0], ev[3])); stats->seconds = ms * 1e-3;
+        PTMI_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); stats->form_factor_ms = ms;
+        PTMI_HIP(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->iteration_ms = ms;
+        PTMI_HIP(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->grid_ms = ms;
+        stats->pairs = (uint64_t)n * (uint64_t)n;
+        unsigned long long rays = 0;
+        PTMI_HIP(hipMemcpy(&rays, d.rays, sizeof rays, hipMemcpyDeviceToHost));
+        stats->rays = rays;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+}
+
+void RadiosityState::readFormFactors(float* out) const {
+    if (!is_calculated) throw ArgError("no radiosity solution");
+    PTMI_HIP(hipMemcpy(out, d.form_factors, (size_t)d.n * (size_t)d.n * sizeof(float), hipMemcpyDeviceToHost));
+}
+
 void SceneState::precomputeCDFs(const float* rgb) {
     if (!d_nodes) throw ArgError("precomputeCDFs: no scene loaded");
     if (d_precomputed_cdfs) { (void)hipFree(d_precomputed_cdfs); d_precomputed_cdfs = nullptr; }

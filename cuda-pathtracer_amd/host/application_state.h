@@ -87,6 +87,27 @@ private:
     void upload();                                   // SoA re-layout + H2D
 };
 
+// RadiosityState — application_state.h:200-216, 688-787: the radiosity pre-pass that produces what the guided sampling
+// modes and the Radiosity integrator read.  Differences by design: the solver works on SoA arrays instead of a device
+// copy of the 4364-byte Primitive records; no n^2 curandStates (streams are derived in the kernel); the reference's
+// per-iteration update_radiosity_grid (+ filter), whose result every later iteration overwrites, runs once at the end;
+// radiosity_history (no reader in the reference outside primitive.h) is not kept.
+struct RadiosityStats { double seconds = 0, form_factor_ms = 0, iteration_ms = 0, grid_ms = 0; uint64_t pairs = 0, rays = 0; };
+struct RadiosityState {
+    int num_iterations = 10, mc_samples = 64;        // application_state.h:208
+    bool use_monte_carlo = true, is_calculated = false;
+    RadiosityBuffers d;                              // device arrays (owned)
+    int final_unshot = 0;                            // which d.unshot[] holds the last iteration's unshot radiosity
+    // results on the host, load order (filled by runSolver)
+    std::vector<float> h_radiosity, h_unshot, h_radiosity_grid;   // n*3, n*3, n*256*3
+    std::vector<float> h_grid;                                     // n*256 visible-sample counts
+    void runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
+                   float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats);
+    void readFormFactors(float* out) const;          // n*n floats, row = receiver
+    void cleanup();                                  // application_state.h:779-787
+    ~RadiosityState() { cleanup(); }
+};
+
 struct RenderState {
     int width = 800, height = 800;                   // DEFAULT_WIDTH/HEIGHT, application_state.h:42-43
     TileMap tile;                                    // rows of the frame this GPU renders
@@ -128,6 +149,7 @@ struct ApplicationState {
     int device_id = 0;
     RenderState render;
     SceneState scene;
+    RadiosityState radiosity;
     AppConfig config;
     std::vector<uint32_t> h_jump;                    // 32 x 160 x 5 words
     std::vector<hipEvent_t> event_pool;

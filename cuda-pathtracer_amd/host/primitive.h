@@ -34,6 +34,19 @@ struct Primitive {
         Primitive p; p.type = PRIM_QUAD; p.v[0] = v00; p.v[1] = v10; p.v[2] = v11; p.v[3] = v01;
         p.bsdf = bsdf; p.normal = unit_vector(cross(v10 - v00, v01 - v00)); return p;
     }
+    // Triangle/Quad::area as their constructors compute it (triangle.h:28,54; quad.h:31): a pure function of the vertices
+    float area() const {
+        if (type == PRIM_TRIANGLE) return 0.5f * length(cross(v[1] - v[0], v[2] - v[0]));
+        return 0.5f * (length(cross(v[1] - v[0], v[3] - v[0])) + length(cross(v[2] - v[1], v[2] - v[3])));
+    }
+    // area1 / (area1 + area2) of Primitive::sampleUniform's quad split (primitive.h:161-170); unused for triangles
+    float sampleAreaRatio() const {
+        if (type == PRIM_TRIANGLE) return 1.0f;
+        const float area1 = 0.5f * length(cross(v[1] - v[0], v[3] - v[0]));
+        const float area2 = 0.5f * length(cross(v[2] - v[1], v[2] - v[3]));
+        const float total_area = area1 + area2;
+        return area1 / total_area;
+    }
     // Primitive::centroid — primitive.h:92-98
     f3 centroid() const {
         if (type == PRIM_TRIANGLE) return div_scalar(v[0] + v[1] + v[2], 3.0f);

@@ -21,6 +21,7 @@ EXPORTS = [
     "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
     "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
     "ptmi_copy_image_device", "ptmi_set_radiosity_grids", "ptmi_get_precomputed_cdfs", "ptmi_set_radiosity",
+           "ptmi_default_radiosity_params", "ptmi_run_radiosity_solver", "ptmi_get_radiosity_solution",
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
@@ -39,6 +40,17 @@ class Config(C.Structure):
 
 class Tiling(C.Structure):
     _fields_ = [("n_ranks", C.c_int), ("rank", C.c_int), ("row_block", C.c_int)]
+
+
+class RadiosityParams(C.Structure):
+    _fields_ = [("num_iterations", C.c_int), ("mc_samples", C.c_int), ("use_monte_carlo", C.c_int),
+                ("enable_filtering", C.c_int), ("use_bilateral", C.c_int),
+                ("filter_sigma_spatial", C.c_float), ("filter_sigma_range", C.c_float)]
+
+
+class RadiosityStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("form_factor_ms", C.c_double), ("iteration_ms", C.c_double), ("grid_ms", C.c_double),
+                ("pairs", C.c_uint64), ("rays", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -89,6 +101,10 @@ def lib():
         L.ptmi_set_radiosity_grids.argtypes = [vp, C.c_int, vp]
         L.ptmi_get_precomputed_cdfs.argtypes = [vp, vp]
         L.ptmi_set_radiosity.argtypes = [vp, C.c_int, vp]
+        L.ptmi_default_radiosity_params.argtypes = [C.POINTER(RadiosityParams)]
+        L.ptmi_default_radiosity_params.restype = None
+        L.ptmi_run_radiosity_solver.argtypes = [vp, C.POINTER(RadiosityParams), C.POINTER(RadiosityStats)]
+        L.ptmi_get_radiosity_solution.argtypes = [vp] * 6
         L.ptmi_debug_intersect.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
         L.ptmi_debug_rng.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_int, vp]
         L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -235,6 +251,30 @@ class Renderer:
         rgb = np.ascontiguousarray(rgb, np.float32)
         assert rgb.ndim == 2 and rgb.shape[1] == 3
         self._ck(self.L.ptmi_set_radiosity(self.h, rgb.shape[0], rgb.ctypes.data))
+
+    def run_radiosity_solver(self, **params):
+        """RadiosityState::runSolver + precomputeCDFs + primitive upload (ui_windows.h:185-192).  Keyword arguments are
+        the fields of ptmi_radiosity_params; defaults are the reference's."""
+        prm = RadiosityParams()
+        self.L.ptmi_default_radiosity_params(C.byref(prm))
+        for k, v in params.items():
+            if k not in dict(RadiosityParams._fields_):
+                raise TypeError(f"unknown radiosity parameter {k}")
+            setattr(prm, k, type(getattr(prm, k))(v))
+        st = RadiosityStats()
+        self._ck(self.L.ptmi_run_radiosity_solver(self.h, C.byref(prm), C.byref(st)))
+        return st
+
+    def radiosity_solution(self, form_factors=True):
+        n = self.scene_info()["n_prims"]
+        out = dict(radiosity=np.zeros((n, 3), np.float32), unshot=np.zeros((n, 3), np.float32),
+                   grid=np.zeros((n, 256), np.float32), radiosity_grid=np.zeros((n, 256, 3), np.float32))
+        if form_factors:
+            out["form_factors"] = np.zeros((n, n), np.float32)
+        self._ck(self.L.ptmi_get_radiosity_solution(self.h, out["form_factors"].ctypes.data if form_factors else None,
+                                                    out["radiosity"].ctypes.data, out["unshot"].ctypes.data,
+                                                    out["grid"].ctypes.data, out["radiosity_grid"].ctypes.data))
+        return out
 
     def precomputed_cdfs(self):
         out = np.zeros((self.scene_info()["n_prims"], 530), np.float32)

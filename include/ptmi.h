@@ -105,6 +105,24 @@ typedef struct {
     uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */
 } ptmi_stats;
 
+/* RadiosityState + the filter switches of AppConfig (application_state.h:207-209, 290-291), defaults in comments */
+typedef struct {
+    int   num_iterations;         /* "Radiosity Steps" 10 (UI range 0..50) */
+    int   mc_samples;             /* 64 (UI range 4..256) */
+    int   use_monte_carlo;        /* 1: calculate_form_factors_mc_kernel, 0: point-to-point calculate_form_factors_kernel */
+    int   enable_filtering;       /* AppConfig::enable_grid_filtering 0 */
+    int   use_bilateral;          /* 1 (0: gaussian) */
+    float filter_sigma_spatial;   /* 1.5 */
+    float filter_sigma_range;     /* 0.3 */
+} ptmi_radiosity_params;
+
+typedef struct {
+    double   seconds;             /* device time of the whole solve */
+    double   form_factor_ms, iteration_ms, grid_ms;
+    uint64_t pairs;               /* n_prims^2 */
+    uint64_t rays;                /* shadow rays cast by the form-factor kernel */
+} ptmi_radiosity_stats;
+
 /* ---- lifetime ------------------------------------------------------------ */
 /* initializeApplication()'s device setup (application.h:92-148). device_id: HIP ordinal. */
 int  ptmi_ctx_create(int device_id, ptmi_ctx** out);
@@ -140,6 +158,18 @@ int ptmi_get_precomputed_cdfs(const ptmi_ctx*, float* out);
 /* Per-primitive radiosity (Triangle/Quad::radiosity; n_prims * 3 floats, load order; NULL = zero) shown by the Radiosity
  * integrator.  Like the grids above it is the radiosity solver's output in the reference and an input here. */
 int ptmi_set_radiosity(ptmi_ctx*, int n_prims, const float* rgb);
+
+/* ---- RadiosityState::runSolver (application_state.h:688-777) + what the UI does right after it (ui_windows.h:185-192):
+ * SceneState::precomputeCDFs() and the upload of the solved primitives.  Runs on the GPU: form factors for all
+ * n_prims^2 pairs (form_factors.h:219-415), num_iterations Jacobi steps (:441-465), the directional radiosity grids
+ * (:405-439) and the optional filter (grid_filter.h).  Afterwards the guided sampling modes and the Radiosity integrator
+ * use the solution, exactly as if ptmi_set_radiosity_grids / ptmi_set_radiosity had been called with it.
+ * The n_prims^2 form factors stay on the device (4 n^2 bytes) until the next solve, scene load or ctx destruction. */
+void ptmi_default_radiosity_params(ptmi_radiosity_params*);
+int ptmi_run_radiosity_solver(ptmi_ctx*, const ptmi_radiosity_params*, ptmi_radiosity_stats* stats /* may be NULL */);
+/* The solution in load order; any pointer may be NULL.  form_factors n*n (row = receiver), radiosity n*3, unshot n*3,
+ * grid n*256 (visible-sample counts per direction cell, Triangle/Quad::grid), radiosity_grid n*256*3. */
+int ptmi_get_radiosity_solution(const ptmi_ctx*, float* form_factors, float* radiosity, float* unshot, float* grid, float* radiosity_grid);
 
 /* ---- RenderState::allocateBuffers / updateResolution (application_state.h:91-129)
  * (Re)allocates the image, path-state and RNG buffers for this rank's rows of a
