@@ -250,6 +250,7 @@ int ptmi_run_radiosity_solver(ptmi_ctx* c, const ptmi_radiosity_params* p, ptmi_
         RadiosityStats st;
         r.runSolver(c->app.scene, c->app.render.d_jump, prm.enable_filtering != 0, prm.use_bilateral != 0,
                     prm.filter_sigma_spatial, prm.filter_sigma_range, c->app.render.stream, &st);
+        c->app.scene.h_count_grids = r.h_grid;                           // Triangle/Quad::grid comes back with the primitives (:773)
         c->app.scene.precomputeCDFs(r.h_radiosity_grid.data());          // ui_windows.h:189
         c->app.scene.setRadiosity(r.h_radiosity.data());                 // ui_windows.h:190-191 (primitive upload)
         if (stats) {
@@ -269,6 +270,31 @@ int ptmi_get_radiosity_solution(const ptmi_ctx* c, float* form_factors, float* r
         if (unshot) std::memcpy(unshot, r.h_unshot.data(), r.h_unshot.size() * sizeof(float));
         if (grid) std::memcpy(grid, r.h_grid.data(), r.h_grid.size() * sizeof(float));
         if (radiosity_grid) std::memcpy(radiosity_grid, r.h_radiosity_grid.data(), r.h_radiosity_grid.size() * sizeof(float));
+    });
+}
+int ptmi_apply_grid_filter(ptmi_ctx* c, int use_bilateral, float sigma_spatial, float sigma_range) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(c->app.scene.d_nodes != nullptr, "no scene loaded");
+        need(sigma_spatial > 0.0f && sigma_range > 0.0f, "filter sigmas must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.scene.precomputeCDFsFromFiltered(use_bilateral != 0, sigma_spatial, sigma_range, c->app.render.stream);
+    });
+}
+int ptmi_use_raw_cdfs(ptmi_ctx* c) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(!c->app.scene.h_radiosity_grids.empty(), "the scene has no radiosity grids");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.scene.precomputeCDFs(c->app.scene.h_radiosity_grids.data());
+    });
+}
+int ptmi_get_filtered_pdfs(const ptmi_ctx* c, float* formfactor, float* radiosity) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(!c->app.scene.h_filtered_radiosity.empty(), "no filtered pdfs (call ptmi_apply_grid_filter first)");
+        if (formfactor) std::memcpy(formfactor, c->app.scene.h_filtered_formfactor.data(), c->app.scene.h_filtered_formfactor.size() * sizeof(float));
+        if (radiosity) std::memcpy(radiosity, c->app.scene.h_filtered_radiosity.data(), c->app.scene.h_filtered_radiosity.size() * sizeof(float));
     });
 }
 int ptmi_get_precomputed_cdfs(const ptmi_ctx* c, float* out) {

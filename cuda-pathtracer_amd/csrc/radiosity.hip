@@ -433,6 +433,48 @@ __global__ __launch_bounds__(kBlock) void ptmi_radiosity_grid(RadiosityBuffers r
     rb.rad_grid[(size_t)i * kGridSize + tid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
 }
 
+// filter_pdfs_for_primitives (grid_filter.h:329-507): luminance of the radiosity grid and the count grid, each through
+// the 5x5 float filter (bilateral :381-406 / gaussian :352-379) and normalize_pdf_kernel (:409-418, a sequential sum).
+__device__ __forceinline__ float filter_cell_float(const float* src, int ci, int cj, bool bilateral, float sigma_spatial, float sigma_range) {
+    const float center = src[ci * kGridRes + cj];
+    float weighted_sum = 0.0f, total_weight = 0.0f;
+    for (int di = -2; di <= 2; di++)
+        for (int dj = -2; dj <= 2; dj++) {
+            const int ni = ci + di, nj = (cj + dj + kGridRes) % kGridRes;
+            if (ni < 0 || ni >= kGridRes) continue;
+            float w = gaussian_weight(sqrt_rn((float)(di * di + dj * dj)), sigma_spatial);
+            if (bilateral) w = w * gaussian_weight(fabsf(center - src[ni * kGridRes + nj]), sigma_range);
+            weighted_sum += src[ni * kGridRes + nj] * w;
+            total_weight += w;
+        }
+    if (total_weight > 1e-6f) return weighted_sum / total_weight;
+    return center;
+}
+__global__ __launch_bounds__(kBlock) void ptmi_filter_pdfs(const float* __restrict__ rgb, const float* __restrict__ counts,
+                                                           float* __restrict__ out_formfactor, float* __restrict__ out_radiosity,
+                                                           int bilateral, float sigma_spatial, float sigma_range) {
+    __shared__ float lum[kGridSize], cnt[kGridSize], f_lum[kGridSize], f_cnt[kGridSize];
+    __shared__ float sums[2];
+    const size_t base = (size_t)blockIdx.x * kGridSize;
+    const int tid = threadIdx.x;
+    const float* c = rgb + (base + tid) * 3;
+    lum[tid] = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2];               // luminanceFromRGB (grid_filter.h:39-41)
+    cnt[tid] = counts ? counts[base + tid] : 0.0f;
+    __syncthreads();
+    f_lum[tid] = filter_cell_float(lum, tid / kGridRes, tid % kGridRes, bilateral != 0, sigma_spatial, sigma_range);
+    f_cnt[tid] = filter_cell_float(cnt, tid / kGridRes, tid % kGridRes, bilateral != 0, sigma_spatial, sigma_range);
+    __syncthreads();
+    if (tid == 0 || tid == 64) {                                               // one lane of two different waves
+        const float* src = tid == 0 ? f_lum : f_cnt;
+        float sum = 0.0f;
+        for (int i = 0; i < kGridSize; i++) sum += src[i];
+        sums[tid ? 1 : 0] = sum;
+    }
+    __syncthreads();
+    out_radiosity[base + tid] = (sums[0] <= 1e-12f) ? f_lum[tid] : f_lum[tid] / sums[0];
+    out_formfactor[base + tid] = (sums[1] <= 1e-12f) ? f_cnt[tid] : f_cnt[tid] / sums[1];
+}
+
 template <bool MC, bool Q_, bool D_>
 void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
     if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
@@ -458,6 +500,13 @@ void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, cons
 void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s) {
     if (rb.n <= 0) return;
     hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rb, src);
+}
+
+void launch_filter_pdfs(int n, const float* d_rgb, const float* d_counts, float* d_out_formfactor, float* d_out_radiosity,
+                        bool bilateral, float sigma_spatial, float sigma_range, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(ptmi_filter_pdfs, dim3(n), dim3(kBlock), 0, s, d_rgb, d_counts, d_out_formfactor, d_out_radiosity,
+                       bilateral ? 1 : 0, sigma_spatial, sigma_range);
 }
 
 void launch_radiosity_grid(const RadiosityBuffers& rb, const RadiosityParams& prm, hipStream_t s) {

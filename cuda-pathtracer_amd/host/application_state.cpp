@@ -85,7 +85,7 @@ void SceneState::cleanup() {
     if (d_precomputed_cdfs) (void)hipFree(d_precomputed_cdfs);
     if (d_radiosity) (void)hipFree(d_radiosity);
     d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr; d_radiosity = nullptr;
-    h_precomputed_cdfs.clear();
+    h_precomputed_cdfs.clear(); h_radiosity_grids.clear(); h_count_grids.clear(); h_filtered_formfactor.clear(); h_filtered_radiosity.clear();
     d_scene = DeviceScene();
     h_primitives.clear(); bvh_nodes.clear(); bvh_indices.clear();
     num_tris = num_quads = 0; bvh_depth = 0;
@@ -317,12 +317,9 @@ void RadiosityState::readFormFactors(float* out) const {
     PTMI_HIP(hipMemcpy(out, d.form_factors, (size_t)d.n * (size_t)d.n * sizeof(float), hipMemcpyDeviceToHost));
 }
 
-void SceneState::precomputeCDFs(const float* rgb) {
-    if (!d_nodes) throw ArgError("precomputeCDFs: no scene loaded");
+void SceneState::buildCdfRecords(const float* pdfs) {
     if (d_precomputed_cdfs) { (void)hipFree(d_precomputed_cdfs); d_precomputed_cdfs = nullptr; }
-    h_precomputed_cdfs.clear();
     d_scene.cdfs = nullptr;
-    if (!rgb) return;
     const int n = (int)h_primitives.size();
     constexpr int GRID_RES = 16, GRID_SIZE = 256, GRID_HALF_RES = 8;
     const float GRID_INV_RES = 1.0f / GRID_RES;
@@ -330,8 +327,7 @@ void SceneState::precomputeCDFs(const float* rgb) {
     for (int p = 0; p < n; p++) {
         float* cdf = &h_precomputed_cdfs[(size_t)p * kCdfDwords];
         float* pdf = cdf + kCdfPdf; float* row_sums = cdf + kCdfRowSums; float* marginal = cdf + kCdfMarginal; float* row_cdfs = cdf + kCdfRowCdfs;
-        const float* g = rgb + (size_t)p * GRID_SIZE * 3;
-        for (int i = 0; i < GRID_SIZE; i++) pdf[i] = 0.2126f * g[3 * i] + 0.7152f * g[3 * i + 1] + 0.0722f * g[3 * i + 2];   // luminance
+        for (int i = 0; i < GRID_SIZE; i++) pdf[i] = pdfs[(size_t)p * GRID_SIZE + i];
         float total_weight = 0.0f;
         for (int v = 0; v < GRID_HALF_RES; v++) {                       // upper hemisphere rows only
             float row_sum = 0.0f;
@@ -361,6 +357,43 @@ void SceneState::precomputeCDFs(const float* rgb) {
     d_precomputed_cdfs = (float*)hipMallocSafe(h_precomputed_cdfs.size() * sizeof(float), "d_precomputed_cdfs");
     PTMI_HIP(hipMemcpy(d_precomputed_cdfs, h_precomputed_cdfs.data(), h_precomputed_cdfs.size() * sizeof(float), hipMemcpyHostToDevice));
     d_scene.cdfs = d_precomputed_cdfs;
+}
+
+void SceneState::precomputeCDFs(const float* rgb) {
+    if (!d_nodes) throw ArgError("precomputeCDFs: no scene loaded");
+    if (d_precomputed_cdfs) { (void)hipFree(d_precomputed_cdfs); d_precomputed_cdfs = nullptr; }
+    h_precomputed_cdfs.clear();
+    d_scene.cdfs = nullptr;
+    h_filtered_formfactor.clear(); h_filtered_radiosity.clear();
+    if (!rgb) { h_radiosity_grids.clear(); return; }
+    const size_t cells = h_primitives.size() * (size_t)kGridSize;
+    if (rgb != h_radiosity_grids.data()) h_radiosity_grids.assign(rgb, rgb + cells * 3);
+    std::vector<float> pdfs(cells);
+    for (size_t i = 0; i < cells; i++) pdfs[i] = 0.2126f * rgb[3 * i] + 0.7152f * rgb[3 * i + 1] + 0.0722f * rgb[3 * i + 2];   // luminance, :516
+    buildCdfRecords(pdfs.data());
+}
+
+void SceneState::precomputeCDFsFromFiltered(bool use_bilateral, float sigma_spatial, float sigma_range, hipStream_t stream) {
+    if (!d_nodes) throw ArgError("precomputeCDFsFromFiltered: no scene loaded");
+    if (h_radiosity_grids.empty()) throw ArgError("precomputeCDFsFromFiltered: the scene has no radiosity grids");
+    const int n = (int)h_primitives.size();
+    const size_t cells = (size_t)n * kGridSize;
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } rgb, cnt, off, orad;
+    rgb.p = hipMallocSafe(cells * 3 * sizeof(float), "d_filter_rgb");
+    off.p = hipMallocSafe(cells * sizeof(float), "d_filtered_formfactor");
+    orad.p = hipMallocSafe(cells * sizeof(float), "d_filtered_radiosity");
+    PTMI_HIP(hipMemcpy(rgb.p, h_radiosity_grids.data(), cells * 3 * sizeof(float), hipMemcpyHostToDevice));
+    if (!h_count_grids.empty()) {
+        cnt.p = hipMallocSafe(cells * sizeof(float), "d_filter_counts");
+        PTMI_HIP(hipMemcpy(cnt.p, h_count_grids.data(), cells * sizeof(float), hipMemcpyHostToDevice));
+    }
+    launch_filter_pdfs(n, (const float*)rgb.p, (const float*)cnt.p, (float*)off.p, (float*)orad.p, use_bilateral, sigma_spatial, sigma_range, stream);
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipStreamSynchronize(stream));
+    h_filtered_formfactor.resize(cells); h_filtered_radiosity.resize(cells);
+    PTMI_HIP(hipMemcpy(h_filtered_formfactor.data(), off.p, cells * sizeof(float), hipMemcpyDeviceToHost));
+    PTMI_HIP(hipMemcpy(h_filtered_radiosity.data(), orad.p, cells * sizeof(float), hipMemcpyDeviceToHost));
+    buildCdfRecords(h_filtered_radiosity.data());
 }
 
 // traversal choice (results are identical in all three; see device_scene.h)

@@ -66,6 +66,13 @@ struct SceneState {
     // order; nullptr drops the records).  The radiosity solver that fills the grids in the reference is out of scope:
     // the grids are an input.
     void precomputeCDFs(const float* radiosity_grids_rgb);
+    // what the radiosity grids / count grids currently are (kept for the filter button); load order
+    std::vector<float> h_radiosity_grids;            // n_prims * 256 * 3, empty = none
+    std::vector<float> h_count_grids;                // n_prims * 256 (Triangle/Quad::grid), empty = zero
+    std::vector<float> h_filtered_formfactor, h_filtered_radiosity;   // n_prims * 256 each, after precomputeCDFsFromFiltered
+    // "Apply Filter & Rebuild CDFs" (ui_windows.h:154-167): filter_pdfs_for_primitives (grid_filter.h:420-507) on the
+    // device, then precomputeCDFsFromFiltered (application_state.h:587-680)
+    void precomputeCDFsFromFiltered(bool use_bilateral, float sigma_spatial, float sigma_range, hipStream_t stream);
     // per-primitive radiosity for the Radiosity integrator (render_radiosity); n_prims*3 floats, load order; nullptr = zero
     float4* d_radiosity = nullptr;
     void setRadiosity(const float* rgb);
@@ -83,6 +90,7 @@ struct SceneState {
     ~SceneState() { cleanup(); }
 
 private:
+    void buildCdfRecords(const float* pdfs);         // application_state.h:509-583 == :609-676, pdfs: n_prims * 256
     void buildBVH();                                 // RayTracingManager::buildAccelStructure (ray_tracing_backend.h:81-129)
     void upload();                                   // SoA re-layout + H2D
 };

@@ -21,7 +21,7 @@ EXPORTS = [
     "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
     "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
     "ptmi_copy_image_device", "ptmi_set_radiosity_grids", "ptmi_get_precomputed_cdfs", "ptmi_set_radiosity",
-           "ptmi_default_radiosity_params", "ptmi_run_radiosity_solver", "ptmi_get_radiosity_solution",
+           "ptmi_apply_grid_filter", "ptmi_use_raw_cdfs", "ptmi_get_filtered_pdfs", "ptmi_default_radiosity_params", "ptmi_run_radiosity_solver", "ptmi_get_radiosity_solution",
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
@@ -101,6 +101,9 @@ def lib():
         L.ptmi_set_radiosity_grids.argtypes = [vp, C.c_int, vp]
         L.ptmi_get_precomputed_cdfs.argtypes = [vp, vp]
         L.ptmi_set_radiosity.argtypes = [vp, C.c_int, vp]
+        L.ptmi_apply_grid_filter.argtypes = [vp, C.c_int, C.c_float, C.c_float]
+        L.ptmi_use_raw_cdfs.argtypes = [vp]
+        L.ptmi_get_filtered_pdfs.argtypes = [vp, vp, vp]
         L.ptmi_default_radiosity_params.argtypes = [C.POINTER(RadiosityParams)]
         L.ptmi_default_radiosity_params.restype = None
         L.ptmi_run_radiosity_solver.argtypes = [vp, C.POINTER(RadiosityParams), C.POINTER(RadiosityStats)]
@@ -251,6 +254,17 @@ class Renderer:
         rgb = np.ascontiguousarray(rgb, np.float32)
         assert rgb.ndim == 2 and rgb.shape[1] == 3
         self._ck(self.L.ptmi_set_radiosity(self.h, rgb.shape[0], rgb.ctypes.data))
+
+    def apply_grid_filter(self, use_bilateral=True, sigma_spatial=1.5, sigma_range=0.3):
+        """"Apply Filter & Rebuild CDFs" (ui_windows.h:154-167); returns the (formfactor, radiosity) filtered pdfs"""
+        self._ck(self.L.ptmi_apply_grid_filter(self.h, int(use_bilateral), sigma_spatial, sigma_range))
+        n = self.scene_info()["n_prims"]
+        ff = np.zeros((n, 256), np.float32); rad = np.zeros((n, 256), np.float32)
+        self._ck(self.L.ptmi_get_filtered_pdfs(self.h, ff.ctypes.data, rad.ctypes.data))
+        return ff, rad
+
+    def use_raw_cdfs(self):
+        self._ck(self.L.ptmi_use_raw_cdfs(self.h))
 
     def run_radiosity_solver(self, **params):
         """RadiosityState::runSolver + precomputeCDFs + primitive upload (ui_windows.h:185-192).  Keyword arguments are

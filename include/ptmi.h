@@ -165,6 +165,15 @@ int ptmi_set_radiosity(ptmi_ctx*, int n_prims, const float* rgb);
  * (:405-439) and the optional filter (grid_filter.h).  Afterwards the guided sampling modes and the Radiosity integrator
  * use the solution, exactly as if ptmi_set_radiosity_grids / ptmi_set_radiosity had been called with it.
  * The n_prims^2 form factors stay on the device (4 n^2 bytes) until the next solve, scene load or ctx destruction. */
+/* "Apply Filter & Rebuild CDFs" (ui_windows.h:154-167): filter_pdfs_for_primitives (grid_filter.h:420-507: luminance of the
+ * radiosity grids and the count grids through the 5x5 bilateral / gaussian float filter, each primitive normalised to
+ * sum 1) + SceneState::precomputeCDFsFromFiltered (application_state.h:587-680): the guided sampling modes then use
+ * records built from the filtered luminance.  Needs radiosity grids (a solver run or ptmi_set_radiosity_grids).
+ * "Use Raw CDFs" (ui_windows.h:173-177) = ptmi_use_raw_cdfs: precomputeCDFs() again from the unfiltered grids. */
+int ptmi_apply_grid_filter(ptmi_ctx*, int use_bilateral, float sigma_spatial, float sigma_range);
+int ptmi_use_raw_cdfs(ptmi_ctx*);
+/* d_filtered_formfactor / d_filtered_radiosity (application_state.h:160-161), n_prims * 256 floats each; either may be NULL */
+int ptmi_get_filtered_pdfs(const ptmi_ctx*, float* formfactor, float* radiosity);
 void ptmi_default_radiosity_params(ptmi_radiosity_params*);
 int ptmi_run_radiosity_solver(ptmi_ctx*, const ptmi_radiosity_params*, ptmi_radiosity_stats* stats /* may be NULL */);
 /* The solution in load order; any pointer may be NULL.  form_factors n*n (row = receiver), radiosity n*3, unshot n*3,

@@ -105,6 +105,8 @@ struct po_scene {
     onode* nodes; int n_nodes, cap_nodes;
     int* indices;
     ocdf* cdfs;               /* Scene::precomputed_cdfs (scene.h:205), NULL until radiosity grids are supplied */
+    v3* rad_grid;             /* Triangle/Quad::radiosity_grid (n * 256), kept for the filter button (ui_windows.h:154-167) */
+    float* count_grid;        /* Triangle/Quad::grid (n * 256), filled by the radiosity solver, NULL = zero */
     v3* radiosity;            /* Triangle/Quad::radiosity per primitive (triangle.h:103), NULL = all zero (as after loading) */
     float mis_bsdf_fraction;  /* Scene::mis_bsdf_fraction, 0.5 (scene.h:217) */
 };
@@ -461,7 +463,7 @@ po_scene* po_scene_from_arrays(int n, const int* type, const float* verts,
     build_bvh(s);
     return s;
 }
-void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s->cdfs); free(s->radiosity); free(s); }
+void po_scene_free(po_scene* s) { if (!s) return; free(s->prims); free(s->nodes); free(s->indices); free(s->cdfs); free(s->radiosity); free(s->rad_grid); free(s->count_grid); free(s); }
 /* per-primitive radiosity (n_prims * 3 floats, load order; NULL = zero): in the reference the radiosity solver's output */
 void po_scene_set_radiosity(po_scene* s, const float* rgb) {
     free(s->radiosity); s->radiosity = NULL;
@@ -473,15 +475,12 @@ void po_scene_set_radiosity(po_scene* s, const float* rgb) {
 /* SceneState::precomputeCDFs (application_state.h:492-585) from per-primitive radiosity grids
  * (rgb: n_prims * 256 * 3 floats, load order).  The grids are an INPUT here: the O(N^2) radiosity
  * solver that fills them in the reference (form_factors.h) is out of scope. */
-void po_scene_set_radiosity_grids(po_scene* s, const float* rgb) {
-    free(s->cdfs); s->cdfs = NULL;
-    if (!rgb) return;
+static void build_cdf_records(po_scene* s, const float* pdfs /* n * 256 */) {   /* application_state.h:509-571 == :609-664 */
+    free(s->cdfs);
     s->cdfs = (ocdf*)calloc((size_t)s->n_prims, sizeof(ocdf));
     for (int p = 0; p < s->n_prims; p++) {
         ocdf* cdf = &s->cdfs[p];
-        const float* g = rgb + (size_t)p * GRID_SIZE * 3;
-        for (int i = 0; i < GRID_SIZE; i++)
-            cdf->pdf[i] = 0.2126f * g[3 * i] + 0.7152f * g[3 * i + 1] + 0.0722f * g[3 * i + 2];
+        for (int i = 0; i < GRID_SIZE; i++) cdf->pdf[i] = pdfs[(size_t)p * GRID_SIZE + i];
         cdf->total_weight = 0.0f;
         for (int v = 0; v < GRID_HALF_RES; v++) {
             float row_sum = 0.0f;
@@ -509,6 +508,18 @@ void po_scene_set_radiosity_grids(po_scene* s, const float* rgb) {
             for (int u = 0; u < GRID_RES; u++) cdf->row_cdfs[v * GRID_RES + u] = (u + 1) * GRID_INV_RES;
         cdf->is_valid = (cdf->total_weight > 1e-6f) ? 1 : 0;
     }
+}
+void po_scene_set_radiosity_grids(po_scene* s, const float* rgb) {
+    free(s->cdfs); s->cdfs = NULL;
+    free(s->rad_grid); s->rad_grid = NULL;
+    if (!rgb) return;
+    const size_t cells = (size_t)s->n_prims * GRID_SIZE;
+    s->rad_grid = (v3*)malloc(sizeof(v3) * cells);
+    memcpy(s->rad_grid, rgb, sizeof(v3) * cells);
+    float* pdfs = (float*)malloc(sizeof(float) * cells);
+    for (size_t i = 0; i < cells; i++) pdfs[i] = 0.2126f * rgb[3 * i] + 0.7152f * rgb[3 * i + 1] + 0.0722f * rgb[3 * i + 2];   /* :516 */
+    build_cdf_records(s, pdfs);
+    free(pdfs);
 }
 void po_scene_set_mis_fraction(po_scene* s, float f) { s->mis_bsdf_fraction = f; }
 /* out: n_prims * 530 floats (the PrecomputedCDF records, is_valid as an int bit pattern) */
@@ -1197,6 +1208,37 @@ static v3 filter_cell(const v3* input_grid, int center_i, int center_j, int bila
     return center_val;
 }
 
+/* rows of the form-factor matrix are independent of each other: a subset, for spot checks at sizes where the whole
+ * matrix is too slow on the CPU.  rows: n_rows receiver indices; out_ff n_rows*n, out_grid n_rows*256 (may be NULL) */
+int po_form_factor_rows(const po_scene* sc, const po_radiosity_params* prm, int n_threads, int n_rows, const int* rows,
+                        float* out_ff, float* out_grid) {
+    if (!sc || !prm || !rows || !out_ff || sc->n_prims > 46340 || prm->mc_samples < 1) return -1;
+    const int n = sc->n_prims;
+    init_jump_tables();
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_num_procs();
+#else
+    n_threads = 1;
+#endif
+    float* area = (float*)malloc(sizeof(float) * (size_t)n);
+    v3* centroid = (v3*)malloc(sizeof(v3) * (size_t)n);
+    v3* radiosity = (v3*)malloc(sizeof(v3) * (size_t)n);
+    for (int i = 0; i < n; i++) { area[i] = prim_area(&sc->prims[i]); centroid[i] = prim_centroid(&sc->prims[i]); radiosity[i] = sc->prims[i].Le; }
+    const solver_geom g = { area, centroid, radiosity };
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int r = 0; r < n_rows; r++) {
+        const int i = rows[r];
+        float grid[GRID_SIZE]; v3 rad_grid[GRID_SIZE]; uint64_t rays = 0;
+        memset(grid, 0, sizeof grid); memset(rad_grid, 0, sizeof rad_grid);
+        for (int j = 0; j < n; j++)
+            out_ff[(size_t)r * n + j] = prm->use_monte_carlo ? form_factor_mc_pair(sc, &g, i, j, prm->mc_samples, grid, rad_grid, &rays)
+                                                             : form_factor_p2p_pair(sc, &g, i, j, &rays);
+        if (out_grid) memcpy(out_grid + (size_t)r * GRID_SIZE, grid, sizeof grid);
+    }
+    free(area); free(centroid); free(radiosity);
+    return 0;
+}
+
 int po_radiosity_solve(po_scene* sc, const po_radiosity_params* prm, int n_threads, float* out_form_factors,
                        float* out_radiosity, float* out_unshot, float* out_grid, float* out_rad_grid, uint64_t* out_rays) {
     if (!sc || !prm || sc->n_prims <= 0 || sc->n_prims > 46340 || prm->num_iterations < 0 || prm->mc_samples < 1) return -1;
@@ -1284,7 +1326,56 @@ int po_radiosity_solve(po_scene* sc, const po_radiosity_params* prm, int n_threa
     /* ui_windows.h:185-192: runSolver; precomputeCDFs(); upload primitives (radiosity now visible to render_radiosity) */
     po_scene_set_radiosity(sc, (const float*)radiosity);
     po_scene_set_radiosity_grids(sc, (const float*)rad_grid);
+    free(sc->count_grid); sc->count_grid = grid; grid = NULL;
     free(area); free(centroid); free(radiosity); free(unshot); free(next_unshot); free(ff); free(grid); free(rad_grid);
+    return 0;
+}
+
+/* "Apply Filter & Rebuild CDFs" (ui_windows.h:154-167): filter_pdfs_for_primitives (grid_filter.h:329-507) on the
+ * count grids and on the luminance of the radiosity grids - 5x5 bilateral or gaussian on floats, then each primitive's
+ * 256 values divided by their sum - followed by precomputeCDFsFromFiltered (application_state.h:587-680), which builds
+ * the CDF records from the filtered luminance.  out_*: n * 256 floats, may be NULL. */
+static float filter_cell_float(const float* src, int ci, int cj, int bilateral, float sigma_spatial, float sigma_range) {
+    const float center = src[ci * GRID_RES + cj];                               /* grid_filter.h:352-367, 381-406 */
+    float weighted_sum = 0.0f, total_weight = 0.0f;
+    for (int di = -BILATERAL_KERNEL_RADIUS; di <= BILATERAL_KERNEL_RADIUS; di++)
+        for (int dj = -BILATERAL_KERNEL_RADIUS; dj <= BILATERAL_KERNEL_RADIUS; dj++) {
+            const int ni = ci + di, nj = (cj + dj + GRID_RES) % GRID_RES;
+            if (ni < 0 || ni >= GRID_RES) continue;
+            float w = gaussian_weight(sqrtf((float)(di * di + dj * dj)), sigma_spatial);
+            if (bilateral) w = w * gaussian_weight(fabsf(center - src[ni * GRID_RES + nj]), sigma_range);
+            weighted_sum += src[ni * GRID_RES + nj] * w;
+            total_weight += w;
+        }
+    if (total_weight > 1e-6f) return weighted_sum / total_weight;
+    return center;
+}
+static void filter_and_normalize(const float* in, float* out, int bilateral, float sigma_spatial, float sigma_range) {
+    for (int c = 0; c < GRID_SIZE; c++) out[c] = filter_cell_float(in, c / GRID_RES, c % GRID_RES, bilateral, sigma_spatial, sigma_range);
+    float sum = 0.0f;                                                           /* normalize_pdf_kernel :409-418 */
+    for (int c = 0; c < GRID_SIZE; c++) sum += out[c];
+    if (sum <= 1e-12f) return;
+    for (int c = 0; c < GRID_SIZE; c++) out[c] = out[c] / sum;
+}
+int po_scene_apply_grid_filter(po_scene* s, int use_bilateral, float sigma_spatial, float sigma_range,
+                               float* out_formfactor, float* out_radiosity) {
+    if (!s || !s->rad_grid) return -1;
+    const int n = s->n_prims;
+    float* ff = (float*)malloc(sizeof(float) * (size_t)n * GRID_SIZE);
+    float* rad = (float*)malloc(sizeof(float) * (size_t)n * GRID_SIZE);
+    for (int p = 0; p < n; p++) {
+        float lum[GRID_SIZE], cnt[GRID_SIZE];
+        for (int c = 0; c < GRID_SIZE; c++) {
+            lum[c] = luminance_from_rgb(s->rad_grid[(size_t)p * GRID_SIZE + c]);   /* compute_radiosity_luminance_kernel :324-336 */
+            cnt[c] = s->count_grid ? s->count_grid[(size_t)p * GRID_SIZE + c] : 0.0f;
+        }
+        filter_and_normalize(cnt, ff + (size_t)p * GRID_SIZE, use_bilateral, sigma_spatial, sigma_range);
+        filter_and_normalize(lum, rad + (size_t)p * GRID_SIZE, use_bilateral, sigma_spatial, sigma_range);
+    }
+    build_cdf_records(s, rad);
+    if (out_formfactor) memcpy(out_formfactor, ff, sizeof(float) * (size_t)n * GRID_SIZE);
+    if (out_radiosity) memcpy(out_radiosity, rad, sizeof(float) * (size_t)n * GRID_SIZE);
+    free(ff); free(rad);
     return 0;
 }
 

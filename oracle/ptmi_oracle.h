@@ -72,6 +72,11 @@ typedef struct {
 } po_radiosity_params;
 int po_radiosity_solve(po_scene*, const po_radiosity_params*, int n_threads, float* out_form_factors, float* out_radiosity,
                        float* out_unshot, float* out_grid, float* out_rad_grid, uint64_t* out_rays);
+/* "Apply Filter & Rebuild CDFs" (ui_windows.h:154-167) on the scene's current grids; -1 without radiosity grids */
+int po_scene_apply_grid_filter(po_scene*, int use_bilateral, float sigma_spatial, float sigma_range,
+                               float* out_formfactor, float* out_radiosity);
+int po_form_factor_rows(const po_scene*, const po_radiosity_params*, int n_threads, int n_rows, const int* rows,
+                        float* out_ff, float* out_grid);
 /* stage hooks for the tests */
 void po_prim_geometry(const po_scene*, int i, float* area, float centroid[3]);
 void po_prim_sample_uniform(const po_scene*, int i, float r1, float r2, float out[3]);

@@ -114,6 +114,10 @@ def oracle_lib():
                                 C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.po_radiosity_solve.restype = C.c_int
         L.po_radiosity_solve.argtypes = [C.c_void_p, C.POINTER(RadiosityParams), C.c_int] + [C.c_void_p] * 6
+        L.po_scene_apply_grid_filter.restype = C.c_int
+        L.po_scene_apply_grid_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.po_form_factor_rows.restype = C.c_int
+        L.po_form_factor_rows.argtypes = [C.c_void_p, C.POINTER(RadiosityParams), C.c_int, C.c_int] + [C.c_void_p] * 3
         L.po_prim_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]
         L.po_prim_sample_uniform.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.po_direction_to_grid_index.restype = C.c_int
@@ -221,6 +225,23 @@ class OracleScene:
             raise RuntimeError(f"po_radiosity_solve failed: {rc}")
         out["rays"] = rays.value
         return out
+
+    def apply_grid_filter(self, use_bilateral=True, sigma_spatial=1.5, sigma_range=0.3):
+        """"Apply Filter & Rebuild CDFs" (ui_windows.h:154-167); returns the filtered, normalised (formfactor, radiosity) pdfs"""
+        ff = np.zeros((self.n_prims, 256), np.float32); rad = np.zeros((self.n_prims, 256), np.float32)
+        rc = self.L.po_scene_apply_grid_filter(self.h, int(use_bilateral), sigma_spatial, sigma_range, ff.ctypes.data, rad.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("apply_grid_filter: the scene has no radiosity grids")
+        return ff, rad
+
+    def form_factor_rows(self, rows, n_threads=0, **params):
+        rows = np.ascontiguousarray(rows, np.int32)
+        prm = RadiosityParams(**params)
+        ff = np.zeros((len(rows), self.n_prims), np.float32); grid = np.zeros((len(rows), 256), np.float32)
+        rc = self.L.po_form_factor_rows(self.h, C.byref(prm), n_threads, len(rows), rows.ctypes.data, ff.ctypes.data, grid.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"po_form_factor_rows failed: {rc}")
+        return ff, grid
 
     def prim_geometry(self, i):
         a = C.c_float(0); c = np.zeros(3, np.float32)

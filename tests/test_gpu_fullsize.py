@@ -140,3 +140,40 @@ def test_config5_one_million_triangles_2048_2048spp(R):
     R.update_resolution(W, H); R.set_config(segments_per_launch=3); R.render_frame()
     assert (bits(R.read_image(rgb8=False)[1]) == bits(full)).all()
     R.set_config(segments_per_launch=0)
+
+
+def test_radiosity_prepass_at_scale(R):
+    """SURVEY 8 f2 at sizes beyond the unit tests: 2048 primitives (4.2 M pairs) compared whole, bit for bit; 8192
+    primitives (67 M pairs, 391 M shadow rays) by 48 random rows of the form-factor matrix and count grid against the
+    oracle plus size-independent properties of the solution."""
+    threads = min(os.cpu_count() or 8, 32)
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path, 3, False)
+    st = R.run_radiosity_solver()
+    got = R.radiosity_solution()
+    o = OracleScene.load(path, 3, False)
+    exp = o.radiosity_solve(n_threads=threads)
+    for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"):
+        assert (bits(got[k]) == bits(exp[k])).all(), k
+    assert st.rays == exp["rays"]
+
+    R.load_scene(path, 4, False)
+    n = R.scene_info()["n_prims"]
+    assert n == 8192
+    st = R.run_radiosity_solver()
+    got = R.radiosity_solution()
+    o = OracleScene.load(path, 4, False)
+    rows = np.random.default_rng(8).choice(n, 48, replace=False)
+    ff, grid = o.form_factor_rows(rows, n_threads=threads)
+    assert (bits(got["form_factors"][rows]) == bits(ff)).all() and (got["grid"][rows] == grid).all()
+    F_ = got["form_factors"]
+    assert (F_ >= 0).all() and (F_ <= 1).all() and (np.diag(F_) == 0).all()
+    assert 0.5 < F_.sum(1).mean() < 1.2                               # closed scene: rows sum to ~1
+    Le = o.prims()["Le"]
+    assert (got["radiosity"] >= Le).all() and np.isfinite(got["radiosity"]).all()
+    g = got["grid"].reshape(n, 16, 16)
+    # directions with cos_theta_i > 0 have theta < pi/2 up to rounding: coplanar neighbours (cos ~ 1e-8) land in row 8
+    assert g.sum() <= st.rays and g[:, 9:].sum() == 0 and g[:, 8].sum() < 1e-3 * g.sum()
+    tot = F_.astype(np.float64) @ got["radiosity"].astype(np.float64)
+    assert np.allclose(got["radiosity_grid"].reshape(n, 256, 3).sum(1), tot, rtol=1e-3, atol=1e-6)
+    R.load_scene(path)

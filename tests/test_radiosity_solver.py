@@ -120,6 +120,36 @@ def test_filters():
     assert np.isfinite(tiny).all()
 
 
+def test_filtered_cdfs_button():
+    """"Apply Filter & Rebuild CDFs" (ui_windows.h:154-167): per-primitive pdfs sum to 1 (or stay all-zero), the CDF
+    records are rebuilt from the filtered luminance, "Use Raw CDFs" restores the unfiltered records."""
+    from guided_fixtures import synthetic_radiosity_grids
+    o = OracleScene.load(CBOX)
+    with pytest.raises(RuntimeError):
+        o.apply_grid_filter()                                              # no grids yet
+    o.radiosity_solve(mc_samples=16)
+    raw = o.cdfs().copy()
+    ff, rad = o.apply_grid_filter()
+    assert np.allclose(rad.sum(1), 1, atol=1e-5) and np.allclose(ff.sum(1), 1, atol=1e-5)
+    assert (rad >= 0).all() and (ff >= 0).all()
+    flt = o.cdfs()
+    assert (flt[:, :256] == rad).all() and (flt.view(np.uint32) != raw.view(np.uint32)).any()
+    assert np.allclose(flt[:, 528], rad.reshape(-1, 16, 16)[:, :8].sum((1, 2)), rtol=1e-5)   # total weight: upper rows only
+    ffg, radg = o.apply_grid_filter(use_bilateral=False, sigma_spatial=0.8)
+    assert (radg != rad).any()
+    # host-supplied grids, no solver: the count grid is zero and stays zero (sum <= 1e-12: not normalised)
+    o2 = OracleScene.load(CBOX)
+    grids = synthetic_radiosity_grids(o2.n_prims)
+    o2.set_radiosity_grids(grids)
+    raw2 = o2.cdfs().copy()
+    ff2, rad2 = o2.apply_grid_filter()
+    assert (ff2 == 0).all()
+    empty = grids.reshape(o2.n_prims, -1).sum(1) == 0
+    assert empty.any() and (rad2[empty] == 0).all() and np.allclose(rad2[~empty].sum(1), 1, atol=1e-5)
+    o2.set_radiosity_grids(grids)                                          # "Use Raw CDFs"
+    assert (o2.cdfs().view(np.uint32) == raw2.view(np.uint32)).all()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def R():
@@ -231,3 +261,41 @@ def test_gpu_solver_deep_tree_and_errors(R):
     R.load_scene(CBOX)
     with pytest.raises(ptmi.PtmiError):
         R.radiosity_solution()                       # a scene load drops the previous solution
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bilateral,ss,sr", [(True, 1.5, 0.3), (False, 1.5, 0.3), (True, 0.6, 0.05), (False, 3.0, 1.0)])
+def test_gpu_filtered_cdfs_match_oracle(R, bilateral, ss, sr):
+    import ptmi
+    from guided_fixtures import synthetic_radiosity_grids
+    path = QUADS
+    R.load_scene(path, 1, False)
+    with pytest.raises(ptmi.PtmiError):
+        R.apply_grid_filter()                                              # no radiosity grids yet
+    R.run_radiosity_solver(mc_samples=8, num_iterations=3)
+    o = OracleScene.load(path, 1, False)
+    o.radiosity_solve(mc_samples=8, num_iterations=3)
+    raw = R.precomputed_cdfs().copy()
+    ff, rad = R.apply_grid_filter(bilateral, ss, sr)
+    off, orad = o.apply_grid_filter(bilateral, ss, sr)
+    assert (bits(ff) == bits(off)).all() and (bits(rad) == bits(orad)).all()
+    assert (R.precomputed_cdfs().view(np.uint32) == o.cdfs().view(np.uint32)).all()
+    # guided rendering uses the filtered records
+    W = H = 40
+    R.update_resolution(W, H); R.set_config(spp=3, sampling_mode=2)
+    R.render_frame()
+    rgb, radi = R.read_image()
+    orgb, oradi, _ = o.render(default_camera(), W, H, 3, sampling_mode=2)
+    assert (bits(radi) == bits(oradi)).all() and (rgb == orgb).all()
+    R.use_raw_cdfs()
+    assert (R.precomputed_cdfs().view(np.uint32) == raw.view(np.uint32)).all()
+    # host-supplied grids (no solver run on this scene): count grids are zero
+    R.load_scene(CBOX)
+    grids = synthetic_radiosity_grids(R.scene_info()["n_prims"])
+    R.set_radiosity_grids(grids)
+    o2 = OracleScene.load(CBOX); o2.set_radiosity_grids(grids)
+    ff, rad = R.apply_grid_filter(bilateral, ss, sr)
+    off, orad = o2.apply_grid_filter(bilateral, ss, sr)
+    assert (ff == 0).all() and (bits(rad) == bits(orad)).all()
+    assert (R.precomputed_cdfs().view(np.uint32) == o2.cdfs().view(np.uint32)).all()
+    R.set_config(sampling_mode=0)
