@@ -186,6 +186,13 @@ int ptmi_host_scene_get_prims(const ptmi_host_scene* s, int* type, float* verts,
 int ptmi_host_scene_get_bvh(const ptmi_host_scene* s, float* bmin, float* bmax, int* left, int* right, int* count, int* indices) {
     return guarded([&] { need(s != nullptr, "scene is NULL"); scene_get_bvh(s->scene, bmin, bmax, left, right, count, indices); });
 }
+int ptmi_write_png(const char* path, int width, int height, const unsigned char* rgb8) {
+    return guarded([&] {
+        need(path && rgb8, "NULL argument");
+        need(width > 0 && height > 0, "width/height must be positive");
+        if (!writePNG(path, width, height, rgb8)) throw IoError(std::string("cannot write ") + path);
+    });
+}
 int ptmi_host_camera_frame(const ptmi_camera* cam, int width, int height, float* out12) {
     return guarded([&] {
         need(cam && out12, "NULL argument");

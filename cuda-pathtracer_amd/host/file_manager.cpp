@@ -1,3 +1,6 @@
+#include <cstdio>
+#include <cstdint>
+#include <algorithm>
 #include "file_manager.h"
 
 #include <fstream>
@@ -170,6 +173,61 @@ std::vector<Primitive> subdivide_primitives(const std::vector<Primitive>& prims,
         cur.swap(next);
     }
     return cur;
+}
+
+namespace {
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void put_chunk(std::vector<unsigned char>& png, const char type[4], const std::vector<unsigned char>& data) {
+    put_be32(png, (uint32_t)data.size());
+    const size_t start = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), data.begin(), data.end());
+    put_be32(png, crc32_update(0xffffffffu, png.data() + start, png.size() - start) ^ 0xffffffffu);
+}
+}  // namespace
+
+bool writePNG(const std::string& path, int width, int height, const unsigned char* rgb) {
+    if (width <= 0 || height <= 0 || !rgb) return false;
+    const size_t stride = (size_t)width * 3;
+    std::vector<unsigned char> raw;                             // filter byte 0 + pixels, top row first
+    raw.reserve((stride + 1) * (size_t)height);
+    for (int y = height - 1; y >= 0; y--) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * stride, rgb + (size_t)(y + 1) * stride);
+    }
+    std::vector<unsigned char> z;                               // zlib: header, stored deflate blocks, adler32
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<unsigned char> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, (uint32_t)width); put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8 bit, RGB
+    put_chunk(png, "IHDR", ihdr);
+    put_chunk(png, "IDAT", z);
+    put_chunk(png, "IEND", {});
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+    return (std::fclose(f) == 0) && ok;
 }
 
 }  // namespace ptmi

@@ -26,4 +26,9 @@ std::vector<Primitive> convertQuadsToTriangles(const std::vector<Primitive>& pri
 // subdivide_primitives — rendering/form_factors.h:520-574
 std::vector<Primitive> subdivide_primitives(const std::vector<Primitive>& prims, int num_subdivisions);
 
+// "Save PNG" (ui/ui_windows.h:195-210: stbi_flip_vertically_on_write(1); stbi_write_png(path, w, h, 3, h_image, w * 3)):
+// 8-bit RGB, rows flipped so that the frame's bottom row (row 0 of the image buffers) ends up last in the file.
+// Own writer (zlib stream of stored blocks); the vendored stb_image_write is third-party code and not reproduced.
+bool writePNG(const std::string& path, int width, int height, const unsigned char* rgb8_bottom_up);
+
 }  // namespace ptmi

@@ -21,7 +21,7 @@ EXPORTS = [
     "ptmi_scene_get_bvh", "ptmi_update_resolution", "ptmi_set_camera", "ptmi_set_config", "ptmi_get_camera_frame",
     "ptmi_local_rows", "ptmi_local_row_map", "ptmi_render_frame", "ptmi_device_image", "ptmi_read_image",
     "ptmi_copy_image_device", "ptmi_set_radiosity_grids", "ptmi_get_precomputed_cdfs", "ptmi_set_radiosity",
-           "ptmi_apply_grid_filter", "ptmi_use_raw_cdfs", "ptmi_get_filtered_pdfs", "ptmi_default_radiosity_params", "ptmi_run_radiosity_solver", "ptmi_get_radiosity_solution",
+           "ptmi_write_png", "ptmi_apply_grid_filter", "ptmi_use_raw_cdfs", "ptmi_get_filtered_pdfs", "ptmi_default_radiosity_params", "ptmi_run_radiosity_solver", "ptmi_get_radiosity_solution",
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
@@ -121,6 +121,7 @@ def lib():
         L.ptmi_host_scene_get_bvh.argtypes = [vp] * 7
         L.ptmi_host_camera_frame.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, vp]
         L.ptmi_host_local_row_map.argtypes = [C.c_int, C.POINTER(Tiling), ip, vp]
+        L.ptmi_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -406,6 +407,13 @@ class Renderer:
         out = np.zeros_like(normals)
         self._ck(self.L.ptmi_debug_cosine_sample(self.h, len(u), normals.ctypes.data, u.ctypes.data, v.ctypes.data, out.ctypes.data))
         return out
+
+
+def write_png(path, rgb8):
+    """"Save PNG" (ui_windows.h:195-210): rgb8 is (H, W, 3) uint8 with row 0 = bottom row, as read_image returns it."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    assert rgb8.ndim == 3 and rgb8.shape[2] == 3
+    _check(lib().ptmi_write_png(os.fsencode(path), rgb8.shape[1], rgb8.shape[0], rgb8.ctypes.data))
 
 
 def render_image(scene_path, width, height, spp, max_depth=5, camera=None, device_id=0, **cfg):

@@ -223,6 +223,9 @@ int  ptmi_host_scene_info(const ptmi_host_scene*, int* n_prims, int* n_tris, int
 int  ptmi_host_scene_get_prims(const ptmi_host_scene*, int* type, float* verts, float* normal, float* bsdf, float* Le);
 int  ptmi_host_scene_get_bvh(const ptmi_host_scene*, float* bmin, float* bmax, int* left, int* right, int* count, int* indices);
 /* Sensor after allocateBuffers() + renderFrame()'s camera update for a width x height frame (12 floats). */
+/* "Save PNG" (ui/ui_windows.h:195-210): 8-bit RGB file of a whole frame as ptmi_read_image returns it (row 0 = bottom);
+ * rows are flipped on write like stbi_flip_vertically_on_write(1) does. */
+int  ptmi_write_png(const char* path, int width, int height, const unsigned char* rgb8_bottom_up);
 int  ptmi_host_camera_frame(const ptmi_camera*, int width, int height, float* out12);
 /* rows of a `height`-row frame owned by `tiling->rank`; rows_out may be NULL to query the count only */
 int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows, int* rows_out);

@@ -152,3 +152,30 @@ def test_c_abi_from_plain_c(tmp_path):
     assert "prims 32 (tris 32 quads 0) bvh nodes 21 depth" in out.stdout
     assert "origin -3.72830215e-07 2.5 8.52936077" in out.stdout
     assert "rank 3 of 8 owns 512 of 4096 rows" in out.stdout
+
+
+def test_png_writer_round_trip(tmp_path):
+    """"Save PNG" (ui_windows.h:195-210): 8-bit RGB, the frame's bottom row (row 0 of the image buffer) last in the file.
+    Decoded here with zlib only: signature, IHDR, CRCs, filter bytes, pixels."""
+    import struct, zlib
+    rng = np.random.default_rng(4)
+    for (h, w) in [(1, 1), (7, 5), (300, 211)]:                     # the last one needs more than one stored deflate block
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / f"t{h}.png")
+        ptmi.write_png(path, img)
+        data = open(path, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos = 8; chunks = []
+        while pos < len(data):
+            n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+            assert crc == zlib.crc32(typ + body) & 0xffffffff
+            chunks.append((typ, body)); pos += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)
+        assert (raw[:, 0] == 0).all()
+        assert (raw[:, 1:].reshape(h, w, 3) == img[::-1]).all()       # flipped: top row first
+    with pytest.raises(ptmi.PtmiError):
+        ptmi.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)
