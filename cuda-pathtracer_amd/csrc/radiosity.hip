@@ -116,23 +116,27 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
                        1.0f / (fabsf(d.z) > 1e-8f ? d.z : 1e-8f));
     const float4* __restrict__ nodes = sc.nodes;
     if (!DEEP) {
+        // while-while: every lane first walks nodes until it stands on a leaf whose box it hits (or runs out of
+        // nodes), then the lanes test their leaves together - node steps and primitive tests do not serialise
         int cur = 0;
-        while (cur < sc.n_nodes) {
-            const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-            const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
-            const bool pass = anyhit_box(n0, n1, o, inv, max_dist);
-            int next = cur + 1;
-            if (!pass && b >= 0) next = a;
-            if (pass && b < 0) {
-                for (int i = 0; i < -b; i++) {
-                    const int k = a + i;
-                    if (k == slot_a || k == slot_b) continue;
-                    if (anyhit_prim<HAS_QUADS>(sc.prims, sc.prim_stride, k, o, d, max_dist)) return true;
-                }
+        const int n_nodes = sc.n_nodes;
+        while (true) {
+            int first = 0, count = 0;
+            while (cur < n_nodes) {
+                const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+                const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+                const bool pass = anyhit_box(n0, n1, o, inv, max_dist);
+                const int here = cur;
+                cur = (!pass && b >= 0) ? a : here + 1;
+                if (pass && b < 0) { first = a; count = -b; break; }
             }
-            cur = next;
+            if (count == 0) return false;
+            for (int i = 0; i < count; i++) {
+                const int k = first + i;
+                if (k == slot_a || k == slot_b) continue;
+                if (anyhit_prim<HAS_QUADS>(sc.prims, sc.prim_stride, k, o, d, max_dist)) return true;
+            }
         }
-        return false;
     } else {
         int stack[32];
         int sp = 0;
@@ -339,20 +343,67 @@ __global__ __launch_bounds__(kBlock) void ptmi_form_factors(DeviceScene sc, Radi
     if (tid == 0 && rb.rays) atomicAdd(rb.rays, (unsigned long long)rays_wg);
 }
 
-// radiosity_iteration_kernel (form_factors.h:441-465): one thread per receiver, ascending j
-__global__ __launch_bounds__(kBlock) void ptmi_radiosity_iterate(RadiosityBuffers rb, int src) {
-    const int n = rb.n;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float* __restrict__ row = rb.form_factors + (size_t)i * (size_t)n;
-    const float4* __restrict__ unshot = rb.unshot[src];
-    f3 incident_rad = mk3(0.0f, 0.0f, 0.0f);
-    for (int j = 0; j < n; ++j) {
-        if (i != j) {
-            const float F_ij = row[j];
-            if (F_ij > 0.0f) incident_rad = incident_rad + F_ij * xyz(unshot[j]);
+// radiosity_iteration_kernel (form_factors.h:441-465): one thread per receiver, ascending j - the float sum is a
+// sequential chain per row, so rows are the only parallelism and the kernel is bound by that chain (~12 VALU ops per
+// j), provided the row data arrive in time: a lane streams its own row in 64-float groups (sixteen 16-byte loads),
+// the NEXT group's loads are issued before the current group is consumed; unshot[] is staged through LDS in chunks and
+// read as a broadcast.  One wave per workgroup, so the 64-row groups spread over as many CUs as possible.
+constexpr int kIterChunk = 1024, kIterBlock = 64, kIterGroup = 64;
+struct RowGroup { float4 q[kIterGroup / 4]; };
+__device__ __forceinline__ void load_group(RowGroup& g, const float* p) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int k = 0; k < kIterGroup / 4; k++) g.q[k] = p4[k];
+}
+__device__ __forceinline__ void consume_group(const RowGroup& g, const float4* u, int j0, int i, f3& incident_rad) {
+#pragma unroll
+    for (int k = 0; k < kIterGroup / 4; k++) {
+        const float f[4] = {g.q[k].x, g.q[k].y, g.q[k].z, g.q[k].w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 uj = u[4 * k + c];
+            const bool take = (j0 + 4 * k + c != i) & (f[c] > 0.0f);
+            const float tx = incident_rad.x + f[c] * uj.x, ty = incident_rad.y + f[c] * uj.y, tz = incident_rad.z + f[c] * uj.z;
+            incident_rad.x = take ? tx : incident_rad.x;            // per component: a struct select goes through scratch
+            incident_rad.y = take ? ty : incident_rad.y;
+            incident_rad.z = take ? tz : incident_rad.z;
         }
     }
+}
+__global__ __launch_bounds__(kIterBlock) void ptmi_radiosity_iterate(RadiosityBuffers rb, int src) {
+    __shared__ float4 u_lds[kIterChunk];
+    const int n = rb.n;
+    const int i = blockIdx.x * kIterBlock + threadIdx.x;
+    const int row_i = min(i, n - 1);                           // lanes past the end walk the last row and store nothing
+    const float* __restrict__ row = rb.form_factors + (size_t)row_i * (size_t)n;
+    const float4* __restrict__ unshot = rb.unshot[src];
+    const int n_vec = (n & 3) == 0 ? (n / kIterGroup) * kIterGroup : 0;   // rows start on 16-byte boundaries only if n % 4 == 0
+    f3 incident_rad = mk3(0.0f, 0.0f, 0.0f);
+    RowGroup ga, gb;
+    if (n_vec > 0) load_group(ga, row);
+    for (int base = 0; base < n; base += kIterChunk) {         // kIterChunk is a multiple of 2 * kIterGroup
+        const int m = min(kIterChunk, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < m; k += kIterBlock) u_lds[k] = unshot[base + k];
+        __syncthreads();
+        int jj = 0;
+        for (; base + jj + 2 * kIterGroup <= n_vec && jj + 2 * kIterGroup <= m; jj += 2 * kIterGroup) {
+            load_group(gb, row + base + jj + kIterGroup);
+            consume_group(ga, u_lds + jj, base + jj, i, incident_rad);
+            if (base + jj + 3 * kIterGroup <= n_vec) load_group(ga, row + base + jj + 2 * kIterGroup);
+            consume_group(gb, u_lds + jj + kIterGroup, base + jj + kIterGroup, i, incident_rad);
+        }
+        if (base + jj + kIterGroup <= n_vec && jj + kIterGroup <= m) {      // an odd group left over at the end of the vector part
+            consume_group(ga, u_lds + jj, base + jj, i, incident_rad);
+            jj += kIterGroup;
+            if (base + jj + kIterGroup <= n_vec) load_group(ga, row + base + jj);
+        }
+        for (; jj < m; jj++) {
+            const float F_ij = row[base + jj];
+            if (base + jj != i && F_ij > 0.0f) incident_rad = incident_rad + F_ij * xyz(u_lds[jj]);
+        }
+    }
+    if (i >= n) return;
     const f3 bsdf = xyz(rb.bsdf[i]);
     const f3 reflected = mk3(fminf(bsdf.x * incident_rad.x, incident_rad.x), fminf(bsdf.y * incident_rad.y, incident_rad.y),
                              fminf(bsdf.z * incident_rad.z, incident_rad.z));
@@ -499,7 +550,7 @@ void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, cons
 
 void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s) {
     if (rb.n <= 0) return;
-    hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rb, src);
+    hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kIterBlock - 1) / kIterBlock), dim3(kIterBlock), 0, s, rb, src);
 }
 
 void launch_filter_pdfs(int n, const float* d_rgb, const float* d_counts, float* d_out_formfactor, float* d_out_radiosity,
