@@ -399,3 +399,33 @@ def test_guided_modes_without_records_equal_bsdf(R):
         R.set_radiosity_grids(np.zeros((31, 256, 3), F))                   # wrong primitive count
     R.set_radiosity_grids(None)
     R.set_config(sampling_mode=0)
+
+
+def test_command_line_caller_writes_the_same_frame(R, tmp_path):
+    """tools/ptmi_render.py (load -> radiosity pre-pass -> MIS-guided frame -> Save PNG) as a child process: the PNG
+    holds the bytes the library returns for the same calls, top row first."""
+    import struct, subprocess, sys, zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "cli.png")
+    scene = os.path.join(SCENES, "cbox.obj")
+    cmd = [sys.executable, os.path.join(root, "tools", "ptmi_render.py"), "--scene", scene, "--width", "96", "--height", "64",
+           "--spp", "3", "--subdivision", "1", "--radiosity", "--mc-samples", "8", "--radiosity-steps", "2", "--sampling-mode", "3", "--out", out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "128 primitives" in res.stdout and "Msamples/s" in res.stdout
+    data = open(out, "rb").read()
+    pos = 8; idat = b""; ihdr = None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        if typ == b"IHDR": ihdr = struct.unpack(">IIBBBBB", data[pos + 8:pos + 8 + n])
+        if typ == b"IDAT": idat += data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    assert ihdr == (96, 64, 8, 2, 0, 0, 0)
+    png = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(64, 1 + 96 * 3)[:, 1:].reshape(64, 96, 3)
+    R.load_scene(scene, 1, False)
+    R.run_radiosity_solver(mc_samples=8, num_iterations=2)
+    R.update_resolution(96, 64); R.set_config(spp=3, max_depth=5, sampling_mode=3)
+    R.render_frame()
+    rgb, _ = R.read_image()
+    assert (png == rgb[::-1]).all()
+    R.set_config(sampling_mode=0)

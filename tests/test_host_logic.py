@@ -179,3 +179,68 @@ def test_png_writer_round_trip(tmp_path):
         assert (raw[:, 1:].reshape(h, w, 3) == img[::-1]).all()       # flipped: top row first
     with pytest.raises(ptmi.PtmiError):
         ptmi.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)
+
+
+def test_loader_differential_fuzz(tmp_path):
+    """300 random OBJ/MTL files from a grammar of everything the reference loader reacts to (and much it ignores):
+    the product's C++ loader (+ conversion, subdivision, BVH) and the oracle's C restatement - written independently
+    from file_manager.h:39-273 - must agree on accept/reject and, where accepted, on every bit."""
+    rng = np.random.default_rng(2024)
+    num = lambda: rng.choice([f"{rng.uniform(-4, 4):.4f}", f"{rng.integers(-3, 4)}", f"{rng.uniform(-1, 1):.3e}", "0", "-0.0", "1e-3", ".5", "+2"])
+    agree_ok = agree_fail = 0
+    for case in range(300):
+        nv = int(rng.integers(0, 9)) if rng.random() < 0.15 else int(rng.integers(3, 10)); nn = int(rng.integers(0, 4))
+        mtl_lines = []
+        for m in range(int(rng.integers(0, 4))):
+            mtl_lines.append(f"newmtl M{m}")
+            for _ in range(int(rng.integers(0, 4))):
+                mtl_lines.append(rng.choice(["Kd", "Ke", "Ks", "Ka", "  Kd", "\tKe", "Ns", "# c", "d"]) + " " + " ".join(num() for _ in range(int(rng.integers(0, 5)))))
+        lines = []
+        if rng.random() < 0.8: lines.append(rng.choice(["mtllib m.mtl", "mtllib missing.mtl", "mtllib"]))
+        for _ in range(nv): lines.append("v " + " ".join(num() for _ in range(int(rng.choice([3, 3, 3, 3, 3, 3, 3, 2, 4])))))
+        for _ in range(nn): lines.append("vn " + " ".join(num() for _ in range(3)))
+        for _ in range(int(rng.integers(0, 10))):
+            kind = rng.random()
+            if kind < 0.15: lines.append(f"usemtl M{rng.integers(0, 5)}")
+            elif kind < 0.25: lines.append(rng.choice(["", "# comment", "o thing", "g grp", "s 1", "vt 0 1", "   ", "f", "v"]))
+            else:
+                k = int(rng.choice([1, 2, 3, 3, 3, 4, 4, 5]))
+                toks = []
+                for _ in range(k):
+                    vi = int(rng.integers(1, nv + 1)) if (nv and rng.random() < 0.93) else int(rng.integers(-1, nv + 3))
+                    form = rng.random()
+                    if form < 0.4: toks.append(f"{vi}")
+                    elif form < 0.6: toks.append(f"{vi}/{rng.integers(0, 3)}")
+                    elif form < 0.85: toks.append(f"{vi}//{rng.integers(0, nn + 2)}")
+                    else: toks.append(f"{vi}/{rng.integers(0, 3)}/{rng.integers(0, nn + 2)}")
+                if rng.random() < 0.1: toks.append("# tail")
+                lines.append("f " + " ".join(toks))
+        d = tmp_path / f"c{case}"; d.mkdir()
+        (d / "m.mtl").write_text("\n".join(mtl_lines) + "\n")
+        (d / "s.obj").write_text("\n".join(lines) + ("\n" if rng.random() < 0.9 else ""))
+        sub = int(rng.integers(0, 3)); conv = bool(rng.random() < 0.5)
+        try:
+            h = ptmi.HostScene.load(str(d / "s.obj"), sub, conv)
+        except ptmi.PtmiError:
+            h = None
+        o = None
+        try:
+            o = OracleScene.load(str(d / "s.obj"), sub, conv)
+        except Exception:
+            o = None
+        assert (h is None) == (o is None), (case, lines)
+        if h is None:
+            agree_fail += 1
+            continue
+        agree_ok += 1
+        hp, op = h.prims(), o.prims()
+        assert (hp["type"] == op["type"]).all(), case
+        tri = hp["type"] == 0
+        assert (bits(hp["verts"][tri][:, :3]) == bits(op["verts"][tri][:, :3])).all() and (bits(hp["verts"][~tri]) == bits(op["verts"][~tri])).all(), case
+        for k in ("normal", "bsdf", "Le"):
+            assert (bits(hp[k]) == bits(op[k])).all(), (case, k)
+        hb, ob = h.bvh(), o.bvh()
+        assert len(hb["left"]) == len(ob["left"]) and (hb["indices"] == ob["indices"]).all() and (hb["count"] == ob["count"]).all(), case
+        assert (bits(hb["bmin"]) == bits(ob["bmin"])).all() and (bits(hb["bmax"]) == bits(ob["bmax"])).all(), case
+    assert agree_ok > 60 and agree_fail > 20, (agree_ok, agree_fail)
+    print(f"loader fuzz: {agree_ok} accepted, {agree_fail} rejected, all agreeing")
