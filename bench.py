@@ -198,6 +198,20 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # The limiter this kernel actually runs into: vector-ALU issue.  VALU wave-instructions per frame are a constant of
+    # the workload (deterministic; SQ_INSTS_VALU of the committed PMC profile, one frame of exactly this configuration);
+    # a SIMD issues at most one per 2.4 clocks for a full-rate stream (tools/valu_rate*.hip), 4 SIMDs x 256 CUs.
+    valu = None
+    pmc_sq = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if world == 1 and side == BASE_SIDE and spp == SPP and os.path.exists(pmc_sq):
+        try:
+            insts = json.load(open(pmc_sq))["ptmi_bounce"]["SQ_INSTS_VALU"]["sum"]
+            per_simd_per_s = insts * args.steps / max(frame_dev_s, 1e-12) / 1024.0
+            valu = {"wave_insts_per_step": insts, "insts_per_simd_per_s": round(per_simd_per_s, 1),
+                    "clocks_per_inst_at_2p4GHz": round(2.4e9 / per_simd_per_s, 3), "full_rate_floor_clocks": 2.4,
+                    "issue_frac": round(2.4 / (2.4e9 / per_simd_per_s), 4)}
+        except Exception:
+            valu = None
     # what this design can send to HBM at all: every queued pixel reads and writes its 88-byte state once per
     # launch (+ 4-byte queue entries); nodes/triangles/materials are LDS-resident for this scene
     state_bytes = visits * (88 + 88 + 4 + 4)
@@ -223,6 +237,7 @@ def main():
                          "achieved_chip": round(local_samples * bytes_per_sample / max(frame_dev_s, 1e-12) / 1e9, 1),
                          "path_state_bytes_per_launch": round(state_bytes / max(launches, 1), 1),
                          "path_state_GBps": round(state_bytes / max(kernel_ms * 1e-3, 1e-12) / 1e9, 1),
+                         "valu": valu,
                          "note": "algorithmic bytes follow SURVEY 8(d) and count node/triangle/material reads as memory "
                                  "traffic; for this 32-triangle scene they are served from LDS, so the kernel is VALU-issue-bound "
                                  "and only the path-state share (path_state_*) can reach HBM"},
