@@ -9,6 +9,7 @@ ORACLE (regression) and give the GPU tests a fixture that does not need the orac
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
+import json
 import os
 import sys
 
@@ -34,3 +35,24 @@ for scene, sub, conv, W, H, spp, depth in CASES:
                         spp=spp, max_depth=depth, rgb8=rgb, radiance=rad,
                         counters=np.array([st.samples, st.rays, st.node_visits, st.prim_tests, st.hits], np.uint64))
     print(name, float(rad.mean()), st.rays / st.samples)
+
+
+# radiosity pre-pass + what it feeds: solver outputs, a MIS-guided frame and a radiosity view
+SOLVER_CASES = [  # scene, subdivision, solver parameters
+    ("cbox.obj", 0, dict()),                                                     # RadiosityState defaults: MC, 64 samples, 10 steps
+    ("cbox_quads.obj", 1, dict(mc_samples=16, num_iterations=3, enable_filtering=True)),
+    ("cbox.obj", 1, dict(use_monte_carlo=False, num_iterations=5)),
+]
+for scene, sub, prm in SOLVER_CASES:
+    o = OracleScene.load(os.path.join(SCENES, scene), sub, False)
+    sol = o.radiosity_solve(**prm)
+    W, H = 48, 40
+    state = np.zeros((H * W, 6), np.uint32)
+    g_rgb, g_rad, _ = o.render(default_camera(), W, H, 4, sampling_mode=3, rng_state=state)
+    v_rgb, v_rad = o.render_radiosity(default_camera(), W, H, 2, rng_state=state, reset_rng=False)
+    name = f"solver_{scene.split('.')[0]}_s{sub}_" + ("default" if not prm else "_".join(f"{k}{int(v)}" for k, v in prm.items())) + ".npz"
+    np.savez_compressed(os.path.join(HERE, name), scene=scene, subdivision=sub, params=json.dumps(prm), width=W, height=H,
+                        form_factors=sol["form_factors"], radiosity=sol["radiosity"], unshot=sol["unshot"], grid=sol["grid"],
+                        radiosity_grid=sol["radiosity_grid"], rays=np.uint64(sol["rays"]), cdfs=o.cdfs(),
+                        guided_rgb8=g_rgb, guided_radiance=g_rad, view_rgb8=v_rgb, view_radiance=v_rad)
+    print(name, float(sol["form_factors"].sum()), float(sol["radiosity"].mean()), sol["rays"])

@@ -2,6 +2,7 @@
 grid_filter.h.  CPU: properties of the oracle's restatement (form_factors.h cannot be compiled here; the primitive.h
 pieces it uses are pinned in test_oracle_vs_ref.py).  GPU: the HIP solver against the oracle, bit for bit - except the
 num_iterations == 0 radiosity grid, which the reference itself accumulates with float atomics in arbitrary order."""
+import json
 import os
 
 import numpy as np
@@ -299,3 +300,49 @@ def test_gpu_filtered_cdfs_match_oracle(R, bilateral, ss, sr):
     assert (ff == 0).all() and (bits(rad) == bits(orad)).all()
     assert (R.precomputed_cdfs().view(np.uint32) == o2.cdfs().view(np.uint32)).all()
     R.set_config(sampling_mode=0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# committed fixtures: tests/golden/solver_*.npz (tests/golden/make_golden.py)
+# ------------------------------------------------------------------------------------------------------------------
+def _solver_fixtures():
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solver_*.npz")))
+    assert len(files) >= 3
+    return files
+
+
+def test_oracle_reproduces_committed_solver_fixtures():
+    for f in _solver_fixtures():
+        g = np.load(f)
+        prm = json.loads(str(g["params"]))
+        o = OracleScene.load(os.path.join(SCENES, str(g["scene"])), int(g["subdivision"]), False)
+        sol = o.radiosity_solve(**prm)
+        for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"):
+            assert (bits(sol[k]) == bits(g[k])).all(), (os.path.basename(f), k)
+        assert sol["rays"] == int(g["rays"]) and (o.cdfs().view(np.uint32) == g["cdfs"].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_committed_solver_fixtures(R):
+    """needs no oracle library: solver outputs, the CDF records, a MIS-guided frame and a radiosity view from the files"""
+    for f in _solver_fixtures():
+        g = np.load(f)
+        prm = json.loads(str(g["params"]))
+        R.load_scene(os.path.join(SCENES, str(g["scene"])), int(g["subdivision"]), False)
+        st = R.run_radiosity_solver(**prm)
+        sol = R.radiosity_solution()
+        for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"):
+            assert (bits(sol[k]) == bits(g[k])).all(), (os.path.basename(f), k)
+        assert st.rays == int(g["rays"]) and (R.precomputed_cdfs().view(np.uint32) == g["cdfs"].view(np.uint32)).all()
+        W, H = int(g["width"]), int(g["height"])
+        R.update_resolution(W, H)
+        R.set_config(spp=4, max_depth=5, sampling_mode=3, integrator=0)
+        R.render_frame()
+        rgb, rad = R.read_image()
+        assert (bits(rad) == bits(g["guided_radiance"])).all() and (rgb == g["guided_rgb8"]).all(), os.path.basename(f)
+        R.set_config(spp=2, integrator=1)
+        R.render_frame()
+        rgb, rad = R.read_image()
+        assert (bits(rad) == bits(g["view_radiance"])).all() and (rgb == g["view_rgb8"]).all(), os.path.basename(f)
+        R.set_config(integrator=0, sampling_mode=0)
