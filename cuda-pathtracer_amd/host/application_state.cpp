@@ -267,8 +267,12 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     prm.enable_filtering = enable_filtering ? 1 : 0; prm.use_bilateral = use_bilateral ? 1 : 0;
     prm.filter_sigma_spatial = filter_sigma_spatial; prm.filter_sigma_range = filter_sigma_range;
 
-    hipEvent_t ev[4];
-    for (auto& e : ev) PTMI_HIP(hipEventCreate(&e));
+    struct Events {                                    // destroyed on every exit path
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } events;
+    hipEvent_t* ev = events.e;
+    for (int k = 0; k < 4; k++) PTMI_HIP(hipEventCreate(&ev[k]));
     PTMI_HIP(hipEventRecord(ev[0], stream));
     launch_form_factors(scene.d_scene, d, prm, d_jump, stream);                       // :726-741
     PTMI_HIP(hipGetLastError());
@@ -309,7 +313,6 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         PTMI_HIP(hipMemcpy(&rays, d.rays, sizeof rays, hipMemcpyDeviceToHost));
         stats->rays = rays;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
 }
 
 void RadiosityState::readFormFactors(float* out) const {

@@ -174,6 +174,8 @@ int ptmi_apply_grid_filter(ptmi_ctx*, int use_bilateral, float sigma_spatial, fl
 int ptmi_use_raw_cdfs(ptmi_ctx*);
 /* d_filtered_formfactor / d_filtered_radiosity (application_state.h:160-161), n_prims * 256 floats each; either may be NULL */
 int ptmi_get_filtered_pdfs(const ptmi_ctx*, float* formfactor, float* radiosity);
+/* (The count grids - Triangle/Quad::grid - are only ever filled by ptmi_run_radiosity_solver; after ptmi_set_radiosity_grids
+ * alone they are zero, as after loadScene in the reference, and the filtered form-factor pdf is all zero.) */
 void ptmi_default_radiosity_params(ptmi_radiosity_params*);
 int ptmi_run_radiosity_solver(ptmi_ctx*, const ptmi_radiosity_params*, ptmi_radiosity_stats* stats /* may be NULL */);
 /* The solution in load order; any pointer may be NULL.  form_factors n*n (row = receiver), radiosity n*3, unshot n*3,
