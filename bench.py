@@ -136,20 +136,31 @@ def main():
 
     # gather plumbing (torch = device memory + RCCL only)
     dev = torch.device("cuda", device_index)
-    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, torch.device("cpu") if args.rehearse_gloo else dev)
+    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, torch.device("cpu") if args.rehearse_gloo else dev, n_send=2)
     assert fg.n_local == n_local_rows
+    slot_free = [None, None]                         # per send buffer: event after the gather that reads it
+    frame_no = [0]
 
     def step(stats):
+        # Frames are independent, so the exchange of frame k overlaps the rendering of frame k + 1: the RCCL gather and
+        # the row placement on rank 0 are only ENQUEUED here (torch's stream); the next render_frame runs on the
+        # library's own streams meanwhile.  A send buffer is reused two frames later, after its gather's event.
+        # Everything outstanding is drained by barrier() (torch.cuda.synchronize) before the clock stops.
         st = r.render_frame(want_stats=stats)
         if use_dist:
+            slot = frame_no[0] & 1
+            frame_no[0] += 1
             if args.rehearse_gloo:
                 rgb, rad = r.read_image()
-                fg.send_rgb[:n_local_rows] = torch.from_numpy(rgb); fg.send_rad[:n_local_rows] = torch.from_numpy(rad)
+                fg.sends_rgb[slot][:n_local_rows] = torch.from_numpy(rgb); fg.sends_rad[slot][:n_local_rows] = torch.from_numpy(rad)
+                fg.gather(slot)
             else:
-                r.copy_image_device(fg.send_rgb.data_ptr(), fg.send_rad.data_ptr())
-            fg.gather()                              # the single RCCL exchange of a frame
-            if not args.rehearse_gloo:
-                torch.cuda.current_stream().synchronize()   # the send buffer is reused by the next frame
+                if slot_free[slot] is not None:
+                    slot_free[slot].synchronize()
+                r.copy_image_device(fg.sends_rgb[slot].data_ptr(), fg.sends_rad[slot].data_ptr())
+                fg.gather(slot)                      # the single RCCL exchange of a frame
+                ev = torch.cuda.Event(); ev.record()
+                slot_free[slot] = ev
         return st
 
     def barrier():

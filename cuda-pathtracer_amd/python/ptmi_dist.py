@@ -17,7 +17,7 @@ def row_maps(height, world, row_block):
 
 
 class FrameGather:
-    def __init__(self, dist, width, height, world, rank, row_block, device, dst=0):
+    def __init__(self, dist, width, height, world, rank, row_block, device, dst=0, n_send=1):
         self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
         self.width, self.height = width, height
         self.maps = row_maps(height, world, row_block)
@@ -26,21 +26,25 @@ class FrameGather:
         # one payload per rank: [float32 radiance | uint8 rgb] so a frame needs exactly ONE collective
         n_px = self.max_rows * width
         self._n_rad_bytes = n_px * 12
-        self.send = torch.zeros(n_px * 15, dtype=torch.uint8, device=device)
-        self.send_rad = self.send[: self._n_rad_bytes].view(torch.float32).view(self.max_rows, width, 3)
-        self.send_rgb = self.send[self._n_rad_bytes:].view(self.max_rows, width, 3)
+        # n_send > 1: a ring of send buffers, so that frame k + 1 can be rendered and staged while the gather of frame k
+        # is still reading its buffer (the caller waits on its own event before reusing a slot)
+        self.sends = [torch.zeros(n_px * 15, dtype=torch.uint8, device=device) for _ in range(max(1, n_send))]
+        self.sends_rad = [b[: self._n_rad_bytes].view(torch.float32).view(self.max_rows, width, 3) for b in self.sends]
+        self.sends_rgb = [b[self._n_rad_bytes:].view(self.max_rows, width, 3) for b in self.sends]
+        self.send, self.send_rad, self.send_rgb = self.sends[0], self.sends_rad[0], self.sends_rgb[0]
         if rank == dst:
-            self.recv = [torch.empty_like(self.send) for _ in range(world)]
+            self.recv = [torch.empty_like(self.sends[0]) for _ in range(world)]
             self.maps_t = [torch.from_numpy(m).to(device) for m in self.maps]
             self.frame_rad = torch.empty((height, width, 3), dtype=torch.float32, device=device)
             self.frame_rgb = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
 
-    def gather(self):
-        """send_rad / send_rgb[:n_local] must hold this rank's rows.  Returns (frame_rad, frame_rgb) on dst, else None."""
+    def gather(self, slot=0):
+        """sends_rad / sends_rgb[slot][:n_local] must hold this rank's rows.  Returns (frame_rad, frame_rgb) on dst, else
+        None.  With the nccl backend the call only enqueues work (collective + row placement) on the current stream."""
         if self.world == 1 and self.dist is None:
-            return self.send_rad[: self.n_local], self.send_rgb[: self.n_local]
+            return self.sends_rad[slot][: self.n_local], self.sends_rgb[slot][: self.n_local]
         is_dst = self.rank == self.dst
-        self.dist.gather(self.send, self.recv if is_dst else None, dst=self.dst)
+        self.dist.gather(self.sends[slot], self.recv if is_dst else None, dst=self.dst)
         if not is_dst:
             return None
         for k in range(self.world):
