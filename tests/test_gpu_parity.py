@@ -442,7 +442,7 @@ def _random_soup(rng, n, quad_frac=0.35, extent=3.0, size=0.6):
     return types, verts, normal.astype(F), bsdf, Le
 
 
-@pytest.mark.parametrize("n,seed,mode", [(7, 1, 0), (60, 2, 0), (64, 3, 3), (65, 4, 0), (400, 5, 2), (3000, 6, 0), (3000, 7, 3)])
+@pytest.mark.parametrize("n,seed,mode", [(1, 8, 0), (2, 9, 3), (7, 1, 0), (60, 2, 0), (64, 3, 3), (65, 4, 0), (400, 5, 2), (3000, 6, 0), (3000, 7, 3)])
 def test_random_soup_frames_match_oracle(R, n, seed, mode):
     """Scenes nothing was tuned on: random BVH shapes on both sides of the 64-primitive sweep limit, leaves of mixed
     triangles and skewed quads, stored normals unrelated to the geometry (the loader keeps the file's normals too),
@@ -463,7 +463,7 @@ def test_random_soup_frames_match_oracle(R, n, seed, mode):
     orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=6, sampling_mode=mode)
     assert_same_image(rgb, rad, orgb, orad, f"soup n={n} mode={mode}")
     assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
-    assert ost.hits > 500 and rad.max() > 0
+    assert n < 7 or (ost.hits > 500 and rad.max() > 0)
     # and the radiosity pre-pass on the same soup (any-hit walk, quad sampling, culling on arbitrary normals)
     if n <= 400:
         R.run_radiosity_solver(mc_samples=6, num_iterations=2)
