@@ -33,7 +33,7 @@ import ptmi  # noqa: E402
 import ptmi_dist  # noqa: E402
 
 SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
-SPP, MAX_DEPTH, BASE_SIDE, ROW_BLOCK = 256, 8, 1024, 8
+SPP, MAX_DEPTH, BASE_SIDE, ROW_BLOCK = 256, 8, 1024, 2   # 2-row blocks: every rank gets exactly side/N rows at N = 1, 2, 4, 8
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
