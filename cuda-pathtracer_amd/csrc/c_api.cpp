@@ -225,6 +225,7 @@ int ptmi_set_radiosity_grids(ptmi_ctx* c, int n_prims, const float* rgb) {
         need(c->app.scene.d_nodes != nullptr, "no scene loaded");
         need(rgb == nullptr || n_prims == (int)c->app.scene.h_primitives.size(), "n_prims does not match the loaded scene");
         PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.radiosity.grids_are_scene_grids = false;               // the caller's grids replace the solver's
         c->app.scene.precomputeCDFs(rgb);
     });
 }
@@ -257,8 +258,12 @@ int ptmi_run_radiosity_solver(ptmi_ctx* c, const ptmi_radiosity_params* p, ptmi_
         RadiosityStats st;
         r.runSolver(c->app.scene, c->app.render.d_jump, prm.enable_filtering != 0, prm.use_bilateral != 0,
                     prm.filter_sigma_spatial, prm.filter_sigma_range, c->app.render.stream, &st);
-        c->app.scene.h_count_grids = r.h_grid;                           // Triangle/Quad::grid comes back with the primitives (:773)
-        c->app.scene.precomputeCDFs(r.h_radiosity_grid.data());          // ui_windows.h:189
+        // the grids (Triangle/Quad::grid, ::radiosity_grid) stay on the device; the host copies the filter button and
+        // "Use Raw CDFs" work from are fetched when one of them is pressed (sync_solver_grids)
+        c->app.scene.h_count_grids.clear(); c->app.scene.h_radiosity_grids.clear();
+        r.grids_are_scene_grids = true;
+        c->app.scene.h_filtered_formfactor.clear(); c->app.scene.h_filtered_radiosity.clear();
+        c->app.scene.precomputeCDFsDevice(r.d.rad_grid, 0, c->app.render.stream);   // ui_windows.h:189, from the solver's device grids
         c->app.scene.setRadiosity(r.h_radiosity.data());                 // ui_windows.h:190-191 (primitive upload)
         if (stats) {
             stats->seconds = st.seconds; stats->form_factor_ms = st.form_factor_ms; stats->iteration_ms = st.iteration_ms;
@@ -272,6 +277,7 @@ int ptmi_get_radiosity_solution(const ptmi_ctx* c, float* form_factors, float* r
         const RadiosityState& r = c->app.radiosity;
         need(r.is_calculated, "no radiosity solution (run ptmi_run_radiosity_solver first)");
         PTMI_HIP(hipSetDevice(c->app.device_id));
+        if (grid || radiosity_grid) const_cast<RadiosityState&>(r).fetchGrids();
         if (form_factors) r.readFormFactors(form_factors);
         if (radiosity) std::memcpy(radiosity, r.h_radiosity.data(), r.h_radiosity.size() * sizeof(float));
         if (unshot) std::memcpy(unshot, r.h_unshot.data(), r.h_unshot.size() * sizeof(float));
@@ -279,20 +285,29 @@ int ptmi_get_radiosity_solution(const ptmi_ctx* c, float* form_factors, float* r
         if (radiosity_grid) std::memcpy(radiosity_grid, r.h_radiosity_grid.data(), r.h_radiosity_grid.size() * sizeof(float));
     });
 }
+// after a solver run the scene's grids live on the device only: bring them to the host side the first time they are needed
+static void sync_solver_grids(ptmi_ctx* c) {
+    RadiosityState& r = c->app.radiosity;
+    if (!r.is_calculated) return;
+    if (c->app.scene.h_count_grids.empty()) { r.fetchGrids(); c->app.scene.h_count_grids = r.h_grid; }
+    if (c->app.scene.h_radiosity_grids.empty() && r.grids_are_scene_grids) { r.fetchGrids(); c->app.scene.h_radiosity_grids = r.h_radiosity_grid; }
+}
 int ptmi_apply_grid_filter(ptmi_ctx* c, int use_bilateral, float sigma_spatial, float sigma_range) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
         need(c->app.scene.d_nodes != nullptr, "no scene loaded");
         need(sigma_spatial > 0.0f && sigma_range > 0.0f, "filter sigmas must be positive");
         PTMI_HIP(hipSetDevice(c->app.device_id));
+        sync_solver_grids(c);
         c->app.scene.precomputeCDFsFromFiltered(use_bilateral != 0, sigma_spatial, sigma_range, c->app.render.stream);
     });
 }
 int ptmi_use_raw_cdfs(ptmi_ctx* c) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
-        need(!c->app.scene.h_radiosity_grids.empty(), "the scene has no radiosity grids");
         PTMI_HIP(hipSetDevice(c->app.device_id));
+        sync_solver_grids(c);
+        need(!c->app.scene.h_radiosity_grids.empty(), "the scene has no radiosity grids");
         c->app.scene.precomputeCDFs(c->app.scene.h_radiosity_grids.data());
     });
 }
@@ -307,8 +322,10 @@ int ptmi_get_filtered_pdfs(const ptmi_ctx* c, float* formfactor, float* radiosit
 int ptmi_get_precomputed_cdfs(const ptmi_ctx* c, float* out) {
     return guarded([&] {
         need(c && out, "NULL argument");
-        need(!c->app.scene.h_precomputed_cdfs.empty(), "no precomputed CDFs");
-        std::memcpy(out, c->app.scene.h_precomputed_cdfs.data(), c->app.scene.h_precomputed_cdfs.size() * sizeof(float));
+        need(c->app.scene.d_precomputed_cdfs != nullptr, "no precomputed CDFs");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        const std::vector<float>& h = const_cast<SceneState&>(c->app.scene).precomputedCdfsHost();
+        std::memcpy(out, h.data(), h.size() * sizeof(float));
     });
 }
 

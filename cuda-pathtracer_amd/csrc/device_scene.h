@@ -141,6 +141,9 @@ void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, cons
 void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s);
 // update_radiosity_grid (form_factors.h:405-439) + the optional filter (grid_filter.h:103-165, 251-312)
 void launch_radiosity_grid(const RadiosityBuffers& rb, const RadiosityParams& prm, hipStream_t s);
+// precomputeCDFs / precomputeCDFsFromFiltered (application_state.h:492-585, 587-680) on the device: n records of kCdfDwords
+// floats from (src_kind 0) float4 radiosity grids, (1) packed float3 grids, (2) pdf values, n * 256 entries each
+void launch_cdf_records(int n, const void* d_src, int src_kind, float* d_out, hipStream_t s);
 // filter_pdfs_for_primitives (grid_filter.h:420-507): d_rgb n*256*3 radiosity grids, d_counts n*256 count grids (or nullptr
 // = zero); outputs n*256 filtered + per-primitive normalised pdfs
 void launch_filter_pdfs(int n, const float* d_rgb, const float* d_counts, float* d_out_formfactor, float* d_out_radiosity,

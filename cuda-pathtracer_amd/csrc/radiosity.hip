@@ -526,6 +526,58 @@ __global__ __launch_bounds__(kBlock) void ptmi_filter_pdfs(const float* __restri
     out_formfactor[base + tid] = (sums[1] <= 1e-12f) ? f_cnt[tid] : f_cnt[tid] / sums[1];
 }
 
+// SceneState::precomputeCDFs / precomputeCDFsFromFiltered (application_state.h:492-585, 587-680): one PrecomputedCDF record
+// per primitive, one thread each - every sum runs in the reference's order.  SRC 0: float4 radiosity grids (the solver's),
+// 1: packed float3 grids (host-supplied), 2: ready pdf values (filtered luminance).
+template <int SRC>
+__global__ __launch_bounds__(kBlock) void ptmi_cdf_records(const void* __restrict__ src, float* __restrict__ out, int n) {
+    // one workgroup per primitive, one thread per cell; the sequential sums are done by one thread per row (and thread 0
+    // for the marginal) from LDS, in the reference's order
+    __shared__ float pdf[kGridSize], row_cdfs[kGridSize], row_sums[kGridRes / 2], marginal[kGridRes / 2];
+    __shared__ float total;
+    constexpr int GRID_HALF_RES = kGridRes / 2;
+    const float GRID_INV_RES = 1.0f / kGridRes;
+    const int p = blockIdx.x, i = threadIdx.x;
+    float v;
+    if (SRC == 0) { const float4 c = static_cast<const float4*>(src)[(size_t)p * kGridSize + i]; v = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+    else if (SRC == 1) { const float* c = static_cast<const float*>(src) + ((size_t)p * kGridSize + i) * 3; v = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
+    else v = static_cast<const float*>(src)[(size_t)p * kGridSize + i];
+    pdf[i] = v;
+    __syncthreads();
+    if (i < GRID_HALF_RES) {
+        float row_sum = 0.0f;
+        for (int u = 0; u < kGridRes; u++) row_sum += pdf[i * kGridRes + u];
+        row_sums[i] = row_sum;
+    }
+    __syncthreads();
+    if (i == 0) {
+        float total_weight = 0.0f;
+        for (int r = 0; r < GRID_HALF_RES; r++) total_weight += row_sums[r];
+        float running = 0.0f;
+        const float inv_total = (total_weight > 1e-6f) ? (1.0f / total_weight) : 0.0f;
+        for (int r = 0; r < GRID_HALF_RES; r++) { running += row_sums[r]; marginal[r] = running * inv_total; }
+        marginal[GRID_HALF_RES - 1] = 1.0f;
+        total = total_weight;
+    }
+    if (i < kGridRes) {                                   // thread i = row i
+        const int ro = i * kGridRes;
+        if (i >= GRID_HALF_RES || row_sums[i] < 1e-6f) {
+            for (int u = 0; u < kGridRes; u++) row_cdfs[ro + u] = (float)(u + 1) * GRID_INV_RES;
+        } else {
+            float running_row = 0.0f;
+            const float inv_row_sum = 1.0f / row_sums[i];
+            for (int u = 0; u < kGridRes; u++) { running_row += pdf[ro + u]; row_cdfs[ro + u] = running_row * inv_row_sum; }
+            row_cdfs[ro + kGridRes - 1] = 1.0f;
+        }
+    }
+    __syncthreads();
+    float* cdf = out + (size_t)p * kCdfDwords;
+    cdf[kCdfPdf + i] = pdf[i];
+    cdf[kCdfRowCdfs + i] = row_cdfs[i];
+    if (i < GRID_HALF_RES) { cdf[kCdfRowSums + i] = row_sums[i]; cdf[kCdfMarginal + i] = marginal[i]; }
+    if (i == 0) { cdf[kCdfTotal] = total; cdf[kCdfValid] = __int_as_float(total > 1e-6f ? 1 : 0); }
+}
+
 template <bool MC, bool Q_, bool D_>
 void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
     if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
@@ -551,6 +603,14 @@ void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, cons
 void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s) {
     if (rb.n <= 0) return;
     hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kIterBlock - 1) / kIterBlock), dim3(kIterBlock), 0, s, rb, src);
+}
+
+void launch_cdf_records(int n, const void* d_src, int src_kind, float* d_out, hipStream_t s) {
+    if (n <= 0) return;
+    const dim3 grid(n), block(kBlock);
+    if (src_kind == 0) hipLaunchKernelGGL(ptmi_cdf_records<0>, grid, block, 0, s, d_src, d_out, n);
+    else if (src_kind == 1) hipLaunchKernelGGL(ptmi_cdf_records<1>, grid, block, 0, s, d_src, d_out, n);
+    else hipLaunchKernelGGL(ptmi_cdf_records<2>, grid, block, 0, s, d_src, d_out, n);
 }
 
 void launch_filter_pdfs(int n, const float* d_rgb, const float* d_counts, float* d_out_formfactor, float* d_out_radiosity,

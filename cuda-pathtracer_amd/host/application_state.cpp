@@ -1,6 +1,7 @@
 #include "application_state.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cstring>
 
@@ -216,7 +217,7 @@ void RadiosityState::cleanup() {
     void* ptrs[] = {(void*)d.geo, (void*)d.slot_of, (void*)d.bsdf, d.radiosity, d.unshot[0], d.unshot[1], d.form_factors, d.grid, d.rad_grid, d.rays};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = RadiosityBuffers();
-    is_calculated = false;
+    is_calculated = false; host_grids_current = false; grids_are_scene_grids = false;
 }
 
 void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
@@ -226,7 +227,11 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     if (n > 46340) throw ArgError("runSolver: more than 46340 primitives (the pair index i * n + j is an int in the reference too)");
     if (num_iterations < 0 || num_iterations > 1000) throw ArgError("runSolver: num_iterations out of range");
     if (mc_samples < 1 || mc_samples > 65536) throw ArgError("runSolver: mc_samples out of range");
+    const bool timing = getenv("PTMI_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     cleanup();                                                                       // :703
+    const double t_cleanup = now();
     // for (i) setRadiosity(Le), setUnshotRad(Le)  (:697-701) + the load-order geometry the kernels sample
     std::vector<float4> geo((size_t)n * 6), bsdf((size_t)n), rad((size_t)n);
     std::vector<int> slot_of((size_t)n);
@@ -271,6 +276,7 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
         ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
     } events;
+    const double t_alloc = now();
     hipEvent_t* ev = events.e;
     for (int k = 0; k < 4; k++) PTMI_HIP(hipEventCreate(&ev[k]));
     PTMI_HIP(hipEventRecord(ev[0], stream));
@@ -285,9 +291,10 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     PTMI_HIP(hipGetLastError());
     PTMI_HIP(hipEventRecord(ev[3], stream));
     PTMI_HIP(hipStreamSynchronize(stream));
+    const double t_kernels = now();
 
     // cudaMemcpy(h_primitives, d_radiosity_primitives, ...) (:773): the solution comes back to the host
-    std::vector<float4> h4((size_t)n * kGridSize);
+    std::vector<float4> h4((size_t)n);
     auto unpack = [&](const float4* dev, size_t count, std::vector<float>& out) {
         PTMI_HIP(hipMemcpy(h4.data(), dev, count * sizeof(float4), hipMemcpyDeviceToHost));
         out.resize(count * 3);
@@ -295,12 +302,10 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     };
     unpack(d.radiosity, (size_t)n, h_radiosity);
     unpack(d.unshot[final_unshot], (size_t)n, h_unshot);
-    unpack(d.rad_grid, (size_t)n * kGridSize, h_radiosity_grid);
-    std::vector<unsigned int> counts((size_t)n * kGridSize);
-    PTMI_HIP(hipMemcpy(counts.data(), d.grid, counts.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    h_grid.resize(counts.size());
-    for (size_t k = 0; k < counts.size(); k++) h_grid[k] = (float)counts[k];
+    h_radiosity_grid.clear(); h_grid.clear(); host_grids_current = false;             // the two big grids stay on the device until asked for
     is_calculated = true;
+    if (timing) fprintf(stderr, "[ptmi] runSolver: cleanup %.1f ms, geometry+alloc+upload %.1f ms, kernels %.1f ms, download %.1f ms\n",
+                        t_cleanup - t_start, t_alloc - t_cleanup, t_kernels - t_alloc, now() - t_kernels);
     if (stats) {
         float ms = 0.0f;
         *stats = RadiosityStats();
@@ -315,51 +320,45 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     }
 }
 
+void RadiosityState::fetchGrids() {
+    if (!is_calculated) throw ArgError("no radiosity solution");
+    if (host_grids_current) return;
+    const size_t cells = (size_t)d.n * kGridSize;
+    std::vector<float4> h4(cells);
+    PTMI_HIP(hipMemcpy(h4.data(), d.rad_grid, cells * sizeof(float4), hipMemcpyDeviceToHost));
+    h_radiosity_grid.resize(cells * 3);
+    for (size_t k = 0; k < cells; k++) { h_radiosity_grid[3 * k] = h4[k].x; h_radiosity_grid[3 * k + 1] = h4[k].y; h_radiosity_grid[3 * k + 2] = h4[k].z; }
+    std::vector<unsigned int> counts(cells);
+    PTMI_HIP(hipMemcpy(counts.data(), d.grid, cells * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    h_grid.resize(cells);
+    for (size_t k = 0; k < cells; k++) h_grid[k] = (float)counts[k];
+    host_grids_current = true;
+}
+
 void RadiosityState::readFormFactors(float* out) const {
     if (!is_calculated) throw ArgError("no radiosity solution");
     PTMI_HIP(hipMemcpy(out, d.form_factors, (size_t)d.n * (size_t)d.n * sizeof(float), hipMemcpyDeviceToHost));
 }
 
-void SceneState::buildCdfRecords(const float* pdfs) {
+void SceneState::precomputeCDFsDevice(const void* d_src, int src_kind, hipStream_t stream) {
+    if (!d_nodes) throw ArgError("precomputeCDFs: no scene loaded");
     if (d_precomputed_cdfs) { (void)hipFree(d_precomputed_cdfs); d_precomputed_cdfs = nullptr; }
+    h_precomputed_cdfs.clear();
     d_scene.cdfs = nullptr;
     const int n = (int)h_primitives.size();
-    constexpr int GRID_RES = 16, GRID_SIZE = 256, GRID_HALF_RES = 8;
-    const float GRID_INV_RES = 1.0f / GRID_RES;
-    h_precomputed_cdfs.assign((size_t)n * kCdfDwords, 0.0f);
-    for (int p = 0; p < n; p++) {
-        float* cdf = &h_precomputed_cdfs[(size_t)p * kCdfDwords];
-        float* pdf = cdf + kCdfPdf; float* row_sums = cdf + kCdfRowSums; float* marginal = cdf + kCdfMarginal; float* row_cdfs = cdf + kCdfRowCdfs;
-        for (int i = 0; i < GRID_SIZE; i++) pdf[i] = pdfs[(size_t)p * GRID_SIZE + i];
-        float total_weight = 0.0f;
-        for (int v = 0; v < GRID_HALF_RES; v++) {                       // upper hemisphere rows only
-            float row_sum = 0.0f;
-            for (int u = 0; u < GRID_RES; u++) row_sum += pdf[v * GRID_RES + u];
-            row_sums[v] = row_sum;
-            total_weight += row_sum;
-        }
-        float running = 0.0f;
-        const float inv_total = (total_weight > 1e-6f) ? (1.0f / total_weight) : 0.0f;
-        for (int v = 0; v < GRID_HALF_RES; v++) { running += row_sums[v]; marginal[v] = running * inv_total; }
-        marginal[GRID_HALF_RES - 1] = 1.0f;
-        for (int v = 0; v < GRID_RES; v++) {
-            const int ro = v * GRID_RES;
-            if (v >= GRID_HALF_RES || row_sums[v] < 1e-6f) {            // empty or lower-hemisphere row: uniform CDF
-                for (int u = 0; u < GRID_RES; u++) row_cdfs[ro + u] = (u + 1) * GRID_INV_RES;
-            } else {
-                float running_row = 0.0f;
-                const float inv_row_sum = 1.0f / row_sums[v];
-                for (int u = 0; u < GRID_RES; u++) { running_row += pdf[ro + u]; row_cdfs[ro + u] = running_row * inv_row_sum; }
-                row_cdfs[ro + GRID_RES - 1] = 1.0f;
-            }
-        }
-        cdf[kCdfTotal] = total_weight;
-        const int valid = total_weight > 1e-6f ? 1 : 0;
-        std::memcpy(&cdf[kCdfValid], &valid, sizeof valid);
-    }
-    d_precomputed_cdfs = (float*)hipMallocSafe(h_precomputed_cdfs.size() * sizeof(float), "d_precomputed_cdfs");
-    PTMI_HIP(hipMemcpy(d_precomputed_cdfs, h_precomputed_cdfs.data(), h_precomputed_cdfs.size() * sizeof(float), hipMemcpyHostToDevice));
+    d_precomputed_cdfs = (float*)hipMallocSafe((size_t)n * kCdfDwords * sizeof(float), "d_precomputed_cdfs");
+    launch_cdf_records(n, d_src, src_kind, d_precomputed_cdfs, stream);
+    PTMI_HIP(hipGetLastError());
+    PTMI_HIP(hipStreamSynchronize(stream));
     d_scene.cdfs = d_precomputed_cdfs;
+}
+
+const std::vector<float>& SceneState::precomputedCdfsHost() {
+    if (h_precomputed_cdfs.empty() && d_precomputed_cdfs) {
+        h_precomputed_cdfs.resize(h_primitives.size() * (size_t)kCdfDwords);
+        PTMI_HIP(hipMemcpy(h_precomputed_cdfs.data(), d_precomputed_cdfs, h_precomputed_cdfs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return h_precomputed_cdfs;
 }
 
 void SceneState::precomputeCDFs(const float* rgb) {
@@ -371,9 +370,10 @@ void SceneState::precomputeCDFs(const float* rgb) {
     if (!rgb) { h_radiosity_grids.clear(); return; }
     const size_t cells = h_primitives.size() * (size_t)kGridSize;
     if (rgb != h_radiosity_grids.data()) h_radiosity_grids.assign(rgb, rgb + cells * 3);
-    std::vector<float> pdfs(cells);
-    for (size_t i = 0; i < cells; i++) pdfs[i] = 0.2126f * rgb[3 * i] + 0.7152f * rgb[3 * i + 1] + 0.0722f * rgb[3 * i + 2];   // luminance, :516
-    buildCdfRecords(pdfs.data());
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } d_rgb;
+    d_rgb.p = hipMallocSafe(cells * 3 * sizeof(float), "d_radiosity_grids_rgb");
+    PTMI_HIP(hipMemcpy(d_rgb.p, rgb, cells * 3 * sizeof(float), hipMemcpyHostToDevice));
+    precomputeCDFsDevice(d_rgb.p, 1, nullptr);
 }
 
 void SceneState::precomputeCDFsFromFiltered(bool use_bilateral, float sigma_spatial, float sigma_range, hipStream_t stream) {
@@ -396,7 +396,7 @@ void SceneState::precomputeCDFsFromFiltered(bool use_bilateral, float sigma_spat
     h_filtered_formfactor.resize(cells); h_filtered_radiosity.resize(cells);
     PTMI_HIP(hipMemcpy(h_filtered_formfactor.data(), off.p, cells * sizeof(float), hipMemcpyDeviceToHost));
     PTMI_HIP(hipMemcpy(h_filtered_radiosity.data(), orad.p, cells * sizeof(float), hipMemcpyDeviceToHost));
-    buildCdfRecords(h_filtered_radiosity.data());
+    precomputeCDFsDevice(orad.p, 2, stream);
 }
 
 // traversal choice (results are identical in all three; see device_scene.h)

@@ -60,7 +60,10 @@ struct SceneState {
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_mats = nullptr;
     DeviceScene d_scene;
     // guided sampling: per-primitive PrecomputedCDF records (render_config.h:24-31), load order
-    std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords
+    std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords: host copy, fetched on demand (precomputedCdfsHost)
+    const std::vector<float>& precomputedCdfsHost();
+    // the records are built on the device (csrc/radiosity.hip: ptmi_cdf_records); d_src: see launch_cdf_records
+    void precomputeCDFsDevice(const void* d_src, int src_kind, hipStream_t stream);
     float* d_precomputed_cdfs = nullptr;
     // precomputeCDFs — application_state.h:492-585, from per-primitive 16x16 radiosity grids (n_prims*256*3 floats, load
     // order; nullptr drops the records).  The radiosity solver that fills the grids in the reference is out of scope:
@@ -90,7 +93,6 @@ struct SceneState {
     ~SceneState() { cleanup(); }
 
 private:
-    void buildCdfRecords(const float* pdfs);         // application_state.h:509-583 == :609-676, pdfs: n_prims * 256
     void buildBVH();                                 // RayTracingManager::buildAccelStructure (ray_tracing_backend.h:81-129)
     void upload();                                   // SoA re-layout + H2D
 };
@@ -109,6 +111,9 @@ struct RadiosityState {
     // results on the host, load order (filled by runSolver)
     std::vector<float> h_radiosity, h_unshot, h_radiosity_grid;   // n*3, n*3, n*256*3
     std::vector<float> h_grid;                                     // n*256 visible-sample counts
+    bool grids_are_scene_grids = false;                            // the scene's radiosity grids are still this solution's
+    bool host_grids_current = false;                               // h_radiosity_grid / h_grid are fetched on demand
+    void fetchGrids();                                             // D2H of the two n*256 grids (33 + 8 MB at n = 8192)
     void runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
                    float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats);
     void readFormFactors(float* out) const;          // n*n floats, row = receiver
