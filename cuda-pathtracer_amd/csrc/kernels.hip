@@ -571,8 +571,10 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
 // for SWEEP), then the traversal stacks (STACK only).
 // amdgpu_num_sgpr(80): with <= 80 SGPRs eight 256-thread workgroups fit a CU instead of six
 // (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
+// GUIDED instantiations would take ~100 VGPRs (4 waves per SIMD); capped at 80 (6 waves, 68 bytes of spills): grid
+// sampling +13 %, MIS +9 % on the benchmark frame (5 waves +8 %, 7 the same as 6, 8 waves +10 % / +3 %).
 template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
+__global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
