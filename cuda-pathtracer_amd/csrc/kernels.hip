@@ -377,16 +377,26 @@ __device__ __forceinline__ int linear_search_cdf(const float* __restrict__ cdf, 
     for (int i = size - 1; i >= 0; i--) if (xi < cdf[i]) r = i;      // first i with xi < cdf[i]
     return r;
 }
+// The cell's solid angle (grid.h:248-252) depends on theta_idx only: the eight values fmaxf(solid_angle, 1e-6f) are
+// evaluated once per workgroup (fill_grid_solid_angles, same expressions) instead of one binary64 sincos per bounce.
+__shared__ float g_grid_solid_angle[8];
+__device__ __forceinline__ void fill_grid_solid_angles() {     // call from block-uniform code, before the first shade_step
+    if (threadIdx.x < 8) {
+        const int theta_idx = threadIdx.x;
+        const float theta_center = (float)((double)(((float)theta_idx + 0.5f) * 0.125f) * (PTMI_PI_D * 0.5f));
+        float st, ct;
+        ptmi_sincosf(theta_center, &st, &ct);
+        const float sin_theta = fmaxf(st, 0.01f);
+        const float solid_angle = (float)(((double)sin_theta * ((PTMI_PI_D * 0.5f) / 8)) * (2.0f * PTMI_PI_D / 16));
+        g_grid_solid_angle[theta_idx] = fmaxf(solid_angle, 1e-6f);
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ float grid_pdf_for_cell(const float* __restrict__ g, int theta_idx, int phi_idx) {   // grid.h:242-253
     const float cell_value = g[kCdfPdf + theta_idx * 16 + phi_idx];
     if (cell_value < 1e-8f) return 1e-6f;
     const float cell_prob = cell_value / fmaxf(g[kCdfTotal], 1e-6f);
-    const float theta_center = (float)((double)(((float)theta_idx + 0.5f) * 0.125f) * (PTMI_PI_D * 0.5f));
-    float st, ct;
-    ptmi_sincosf(theta_center, &st, &ct);
-    const float sin_theta = fmaxf(st, 0.01f);
-    const float solid_angle = (float)(((double)sin_theta * ((PTMI_PI_D * 0.5f) / 8)) * (2.0f * PTMI_PI_D / 16));
-    return cell_prob / fmaxf(solid_angle, 1e-6f);
+    return cell_prob / g_grid_solid_angle[theta_idx];
 }
 __device__ __forceinline__ f3 grid_sample(const float* __restrict__ g, f3 normal, Rng& rng, float& out_pdf) {   // grid.h:141-188
     const float xi1 = rng_uniform(rng);
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_s
     const float4 *nodes, *prims, *mats;
     float4* lds = stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
     int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
+    if (GUIDED) fill_grid_solid_angles();
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool active = idx < n_in;
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
     const float4 *nodes, *prims, *mats;
     stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
+    if (GUIDED) fill_grid_solid_angles();
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool active = idx < n_in;
