@@ -681,6 +681,7 @@ int po_rng_selftest(int log2n, const uint32_t v_in[5]) {
 void po_sincosf(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }
 float po_powf(float x, float y) { return ptmi_powf(x, y); }
 float po_acosf(float x) { return ptmi_acosf(x); }
+float po_expf(float x) { return ptmi_expf(x); }
 float po_atan2f(float y, float x) { return ptmi_atan2f(y, x); }
 
 /* ------------------------------------------------------------------------ */

@@ -78,6 +78,7 @@ int po_scene_apply_grid_filter(po_scene*, int use_bilateral, float sigma_spatial
 int po_form_factor_rows(const po_scene*, const po_radiosity_params*, int n_threads, int n_rows, const int* rows,
                         float* out_ff, float* out_grid);
 /* stage hooks for the tests */
+float po_expf(float x);
 void po_prim_geometry(const po_scene*, int i, float* area, float centroid[3]);
 void po_prim_sample_uniform(const po_scene*, int i, float r1, float r2, float out[3]);
 int po_direction_to_grid_index(const float dir[3], const float normal[3]);

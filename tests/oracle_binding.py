@@ -108,6 +108,7 @@ def oracle_lib():
         L.po_render_radiosity.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.po_acosf.restype = C.c_float; L.po_acosf.argtypes = [C.c_float]
+        L.po_expf.restype = C.c_float; L.po_expf.argtypes = [C.c_float]
         L.po_atan2f.restype = C.c_float; L.po_atan2f.argtypes = [C.c_float, C.c_float]
         L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

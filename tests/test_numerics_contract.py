@@ -43,6 +43,25 @@ def test_powf_gamma():
     assert L.po_powf(0.0, float(g)) == 0.0 and L.po_powf(1.0, float(g)) == 1.0
 
 
+def test_expf_for_the_filter_weights():
+    """ptmi_expf (grid_filter.h:35-37 gaussianWeight): correctly rounded on > 99.99 % of the range the filters use
+    (x <= 0), exact limits: exp(0) = 1, underflow to 0 below -104, denormal results, +inf above 88.75, NaN through."""
+    L = oracle_lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([-rng.uniform(0, 20, 20000), -10.0 ** rng.uniform(-30, 2, 5000), rng.uniform(0, 80, 2000),
+                         [0.0, -0.0, -87.3, -88.0, -95.0, -103.0, -103.9]]).astype(F)
+    got = np.array([L.po_expf(float(x)) for x in xs], F)
+    ref = np.exp(xs.astype(np.float64))
+    with np.errstate(over="ignore", under="ignore"):
+        cr = ref.astype(F)
+    assert (got == cr).mean() > 0.9999
+    ulp = np.spacing(np.maximum(np.abs(cr), np.finfo(F).tiny)).astype(np.float64)
+    assert (np.abs(got.astype(np.float64) - ref) <= 0.5000001 * ulp + 1e-45).all()
+    assert L.po_expf(0.0) == 1.0 and L.po_expf(-104.5) == 0.0 and L.po_expf(-1e30) == 0.0
+    assert 0.0 < L.po_expf(-100.0) < np.finfo(F).tiny                       # denormal, not flushed
+    assert L.po_expf(89.0) == np.inf and np.isnan(L.po_expf(float("nan")))
+
+
 def test_xorwow_matrix_powers_equal_direct_stepping():
     L = oracle_lib()
     L.po_rng_selftest.argtypes = [C.c_int, C.c_void_p]
