@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libptmi_oracle.so")
+ORACLE_SO = os.environ.get("PTMI_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libptmi_oracle.so")   # override: sanitizer builds of the checker
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libptmi_ref.so")
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
