@@ -472,3 +472,67 @@ def test_random_soup_frames_match_oracle(R, n, seed, mode):
         for k in ("form_factors", "radiosity", "grid", "radiosity_grid"):
             assert (bits(got[k]) == bits(exp[k])).all(), k
     R.set_config(sampling_mode=0, collect_stats=False)
+
+
+def _degenerate_scene(rng, quads):
+    """the Cornell box plus everything a sloppy exporter produces: zero-area and collinear triangles, duplicated vertices,
+    edges of 1e-20 and of 1e6, exactly axis-aligned faces through the camera's view, faces coplanar with box walls,
+    primitives behind the camera, bow-tie (self-intersecting) quads, normals of length 0"""
+    o = OracleScene.load(os.path.join(SCENES, "cbox_quads.obj" if quads else "cbox.obj"))
+    p = o.prims()
+    types = list(p["type"]); verts = [v.copy() for v in p["verts"]]; normal = list(p["normal"]); bsdf = list(p["bsdf"]); Le = list(p["Le"])
+
+    def add(t, vs, n=(0, 0, 1), kd=(0.6, 0.5, 0.4), le=(0, 0, 0)):
+        v = np.zeros((4, 3), F); v[:len(vs)] = np.asarray(vs, F)
+        types.append(t); verts.append(v); normal.append(np.asarray(n, F)); bsdf.append(np.asarray(kd, F)); Le.append(np.asarray(le, F))
+
+    c = np.array([0.0, 2.5, -2.0], F)
+    add(0, [c, c, c])                                                    # a point
+    add(0, [c, c + [1, 0, 0], c + [2, 0, 0]])                            # collinear
+    add(0, [c, c + [1, 0, 0], c])                                        # duplicated vertex
+    add(0, [c, c + [1e-20, 0, 0], c + [0, 1e-20, 0]])                    # denormal-scale determinant
+    add(0, [c + [0, 0, 1], c + [1e-4, 0, 1], c + [0, 1e-4, 1]], le=(3, 3, 3))   # tiny but valid emitter
+    add(0, [[-1e6, 0.5, -3], [1e6, 0.5, -3], [0, 0.5, 1e6]], n=(0, 1, 0))        # huge, axis-aligned, cuts through the box
+    add(0, [[-1, 1, -1], [1, 1, -1], [0, 3, -1]], n=(0, 0, 0))                   # zero normal
+    add(0, [[-1, 1, 20], [1, 1, 20], [0, 3, 20]])                                # behind the camera
+    if quads:
+        add(1, [c, c, c, c])                                             # degenerate quad
+        add(1, [[-1, 1, -2], [1, 1, -2], [-1, 3, -2], [1, 3, -2]])       # bow-tie
+        add(1, [[-0.5, 0.2, -1], [0.5, 0.2, -1], [0.5, 0.2, -2], [-0.5, 0.2, -2]], n=(0, 1, 0), le=(0.5, 0.5, 2))   # axis-aligned emitter
+    wall = verts[2].copy()
+    add(int(types[2]), wall[:4 if types[2] else 3], n=normal[2], kd=(0.9, 0.1, 0.1))   # exact duplicate of an existing face
+    return (np.array(types, np.int32), np.stack(verts).astype(F), np.stack(normal).astype(F), np.stack(bsdf).astype(F), np.stack(Le).astype(F))
+
+
+@pytest.mark.parametrize("quads", [False, True])
+def test_degenerate_geometry_matches_oracle(R, quads):
+    rng = np.random.default_rng(13)
+    arrs = _degenerate_scene(rng, quads)
+    R.load_scene_arrays(*arrs)
+    o = OracleScene.from_arrays(*arrs)
+    O, D = _test_rays(o, rng, 3000)
+    g = R.debug_intersect(O, D)
+    for i in range(len(O)):
+        h = o.intersect(O[i], D[i])
+        assert g["hit"][i] == h.hit and g["prim"][i] == h.prim, i
+        if h.hit:
+            assert bits(g["t"][i]) == bits(F(h.t))
+    W, H, spp = 72, 64, 8
+    R.update_resolution(W, H)
+    for mode in (-1, R.LANE, R.PHASED):
+        R.set_traversal(mode)
+        R.update_resolution(W, H)
+        R.set_config(spp=spp, max_depth=6, collect_stats=True)
+        st = R.render_frame()
+        rgb, rad = R.read_image()
+        orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=6)
+        assert_same_image(rgb, rad, orgb, orad, f"degenerate quads={quads} mode={mode}")
+        assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+    R.set_traversal(-1)
+    R.run_radiosity_solver(mc_samples=8, num_iterations=2)
+    got = R.radiosity_solution()
+    exp = o.radiosity_solve(mc_samples=8, num_iterations=2)
+    for k in ("form_factors", "radiosity", "grid"):
+        same = (bits(got[k]) == bits(exp[k])) | (np.isnan(got[k]) & np.isnan(exp[k]))
+        assert same.all(), (k, int((~same).sum()))
+    R.set_config(collect_stats=False)
