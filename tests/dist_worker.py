@@ -25,6 +25,34 @@ def main():
     o = OracleScene.load(os.path.join(SCENES, "cbox.obj"))
     rows = ptmi_dist.row_maps(H, world, row_block)[rank]
     assert (rows == ptmi.host_local_row_map(H, world, rank, row_block)).all()
+    if len(sys.argv) > 5 and sys.argv[5] == "gpu":
+        # the product path: every rank renders ITS tile on the GPU (all ranks share device 0 here), two frames with the
+        # ring of send buffers bench.py uses; rank 0 checks the second gathered frame against the unsharded oracle frame
+        r = ptmi.Renderer(0)
+        r.load_scene(os.path.join(SCENES, "cbox.obj"))
+        r.update_resolution(W, H, n_ranks=world, rank=rank, row_block=row_block)
+        r.set_config(spp=spp, max_depth=5)
+        fg2 = ptmi_dist.FrameGather(dist, W, H, world, rank, row_block, torch.device("cpu"), n_send=2)
+        state = np.zeros((H * W, 6), np.uint32)
+        out = None
+        for frame in range(2):
+            r.render_frame()
+            rgb, rad = r.read_image()
+            fg2.sends_rgb[frame & 1][: len(rows)] = torch.from_numpy(rgb); fg2.sends_rad[frame & 1][: len(rows)] = torch.from_numpy(rad)
+            out = fg2.gather(frame & 1)
+        r.close()
+        ok = True
+        if rank == 0:
+            frad, frgb = out
+            for frame in range(2):
+                orgb, orad, _ = o.render(default_camera(), W, H, spp, n_threads=2, rng_state=state, reset_rng=(frame == 0))
+            ok = bool((frad.numpy().view(np.uint32) == orad.view(np.uint32)).all() and (frgb.numpy() == orgb).all())
+            print("dist-gather-gpu", "OK" if ok else "MISMATCH", W, H, world, row_block, flush=True)
+        flag = torch.tensor([1 if ok else 0])
+        dist.broadcast(flag, src=0)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if int(flag.item()) == 1 else 1)
     # contiguous runs of rows -> one oracle call each (rows [y0, y1) of the full frame)
     rad = np.zeros((H, W, 3), np.float32); rgb = np.zeros((H, W, 3), np.uint8)
     y = 0

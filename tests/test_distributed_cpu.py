@@ -23,3 +23,17 @@ def test_gloo_tile_gather_reassembles_the_frame(world, W, H, row_block):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "dist-gather OK" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,W,H,row_block", [(2, 96, 70, 2), (4, 64, 64, 8), (3, 50, 33, 1)])
+def test_gloo_ranks_render_their_tiles_on_the_gpu(world, W, H, row_block):
+    """the product path under N > 1: every rank drives its own ptmi_ctx (sharing the one GPU of the test box), renders its
+    interleaved row blocks, and the gathered second frame equals the unsharded oracle frame bit for bit"""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "dist_worker.py"), str(W), str(H), "3", str(row_block), "gpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "dist-gather-gpu OK" in p.stdout
