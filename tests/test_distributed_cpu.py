@@ -37,3 +37,18 @@ def test_gloo_ranks_render_their_tiles_on_the_gpu(world, W, H, row_block):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "dist-gather-gpu OK" in p.stdout
+
+
+@pytest.mark.gpu
+def test_bench_exchange_path_through_rccl_with_one_rank():
+    """bench.py's N > 1 code path (process group "nccl" = RCCL, device-to-device staging, pipelined gather) with a world of
+    one rank - all that a one-GPU box can run of it - must produce a valid line."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist",
+                        "--no-cpu", "--spp", "8"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 100 and line["unit"] == "Msamples/s"
+    assert line["roofline"]["bound"] == "hbm" and "cpu_baseline" not in line
