@@ -536,3 +536,26 @@ def test_degenerate_geometry_matches_oracle(R, quads):
         same = (bits(got[k]) == bits(exp[k])) | (np.isnan(got[k]) & np.isnan(exp[k]))
         assert same.all(), (k, int((~same).sum()))
     R.set_config(collect_stats=False)
+
+
+def test_whole_path_from_plain_c(R, tmp_path):
+    """examples/render_frame.c (C99): solver, guided frame, radiosity view and PNG through the C ABI; the frame it reports
+    is the one the Python binding gets for the same calls."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "cuda-pathtracer_amd")
+    exe = tmp_path / "render_frame"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "render_frame.c"),
+                           "-L" + libdir, "-lptmi", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    png = tmp_path / "c.png"
+    out = subprocess.run([str(exe), os.path.join(SCENES, "cbox.obj"), str(png)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "radiosity: 128 primitives, 16384 pairs" in out.stdout and png.stat().st_size > 160 * 120 * 3
+    R.load_scene(os.path.join(SCENES, "cbox.obj"), 1, False)
+    R.run_radiosity_solver(mc_samples=16, num_iterations=4)
+    R.update_resolution(160, 120); R.set_config(spp=8, max_depth=5, sampling_mode=3)
+    R.render_frame()
+    _, rad = R.read_image()
+    mean = float(rad.astype(np.float64).sum() / rad.size)
+    assert f"mean radiance {mean:.6f}" in out.stdout, (mean, out.stdout)
+    R.set_config(sampling_mode=0)
