@@ -208,6 +208,14 @@ int ptmi_host_camera_frame(const ptmi_camera* cam, int width, int height, float*
         for (int i = 0; i < 4; i++) { out12[3 * i] = v[i].x; out12[3 * i + 1] = v[i].y; out12[3 * i + 2] = v[i].z; }
     });
 }
+int ptmi_host_cdf_record_layout(int* out10) {
+    return guarded([&] {
+        need(out10 != nullptr, "NULL argument");
+        const int v[10] = {kCdfDwords * 4, kCdfPdf * 4, kCdfRowSums * 4, kCdfMarginal * 4, kCdfRowCdfs * 4, kCdfTotal * 4, kCdfValid * 4,
+                           kGridRes, kGridSize, kGridRes / 2};
+        std::memcpy(out10, v, sizeof v);
+    });
+}
 int ptmi_host_local_row_map(int height, const ptmi_tiling* t, int* n_rows, int* rows_out) {
     return guarded([&] {
         need(t && n_rows, "NULL argument");

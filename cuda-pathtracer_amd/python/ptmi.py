@@ -25,6 +25,7 @@ EXPORTS = [
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
+    "ptmi_host_cdf_record_layout",
 ]
 
 
@@ -122,6 +123,7 @@ def lib():
         L.ptmi_host_camera_frame.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, vp]
         L.ptmi_host_local_row_map.argtypes = [C.c_int, C.POINTER(Tiling), ip, vp]
         L.ptmi_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
+        L.ptmi_host_cdf_record_layout.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -194,6 +196,12 @@ def host_local_row_map(height, n_ranks, rank, row_block):
     if n.value:
         _check(lib().ptmi_host_local_row_map(int(height), C.byref(t), C.byref(n), rows.ctypes.data))
     return rows
+
+
+def host_cdf_record_layout():
+    out = np.zeros(10, np.int32)
+    _check(lib().ptmi_host_cdf_record_layout(out.ctypes.data))
+    return out
 
 
 def default_camera():

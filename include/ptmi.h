@@ -229,6 +229,10 @@ int  ptmi_host_scene_get_bvh(const ptmi_host_scene*, float* bmin, float* bmax, i
  * rows are flipped on write like stbi_flip_vertically_on_write(1) does. */
 int  ptmi_write_png(const char* path, int width, int height, const unsigned char* rgb8_bottom_up);
 int  ptmi_host_camera_frame(const ptmi_camera*, int width, int height, float* out12);
+/* Layout of one PrecomputedCDF record as ptmi_get_precomputed_cdfs returns it and as the kernels read it
+ * (render_config.h:24-31): out[0] = bytes per record, out[1..6] = byte offsets of pdf, row_sums, marginal_cdf, row_cdfs,
+ * total_weight, is_valid; out[7..9] = GRID_RES, GRID_SIZE, GRID_HALF_RES (render_config.h:7-9). */
+int  ptmi_host_cdf_record_layout(int* out10);
 /* rows of a `height`-row frame owned by `tiling->rank`; rows_out may be NULL to query the count only */
 int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows, int* rows_out);
 

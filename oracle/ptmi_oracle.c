@@ -30,6 +30,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -527,6 +528,18 @@ int po_scene_get_cdfs(const po_scene* s, float* out) {
     if (!s->cdfs) return 0;
     memcpy(out, s->cdfs, (size_t)s->n_prims * sizeof(ocdf));
     return 1;
+}
+/* the restatement's view of render_config.h:8-31, 14-17 - compared with the reference's own compiler pass
+ * (oracle/ref_harness.cpp: ref_layout, ref_grid_constants) in tests/test_oracle_vs_ref.py */
+void po_cdf_layout(int out[10]) {
+    out[0] = (int)sizeof(ocdf); out[1] = (int)offsetof(ocdf, pdf); out[2] = (int)offsetof(ocdf, row_sums);
+    out[3] = (int)offsetof(ocdf, marginal_cdf); out[4] = (int)offsetof(ocdf, row_cdfs);
+    out[5] = (int)offsetof(ocdf, total_weight); out[6] = (int)offsetof(ocdf, is_valid);
+    out[7] = GRID_RES; out[8] = GRID_SIZE; out[9] = GRID_HALF_RES;
+}
+void po_grid_constants(double out[6]) {
+    out[0] = (double)GRID_INV_RES; out[1] = (double)GRID_INV_HALF_RES; out[2] = (double)GRID_D_THETA; out[3] = (double)GRID_D_PHI;
+    out[4] = (double)PTMI_PI_D; out[5] = (double)(PTMI_PI_D * 0.5f);
 }
 int po_scene_num_prims(const po_scene* s) { return s->n_prims; }
 int po_scene_num_nodes(const po_scene* s) { return s->n_nodes; }

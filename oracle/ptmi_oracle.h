@@ -84,6 +84,8 @@ void po_prim_sample_uniform(const po_scene*, int i, float r1, float r2, float ou
 int po_direction_to_grid_index(const float dir[3], const float normal[3]);
 int po_visibility_blocked(const po_scene*, const float o[3], const float d[3], float max_dist, int source_idx, int target_idx);
 int po_scene_get_cdfs(const po_scene*, float* out /* n_prims * 530 floats */);
+void po_cdf_layout(int out[10]);          /* sizeof + field offsets of the PrecomputedCDF restatement, GRID_RES / _SIZE / _HALF_RES */
+void po_grid_constants(double out[6]);    /* GRID_INV_RES, GRID_INV_HALF_RES, GRID_D_THETA, GRID_D_PHI, M_PI, M_PI * 0.5f */
 
 /* camera, rng, numerics -------------------------------------------------- */
 void po_camera_frame_setup(const po_camera*, int width, int height, po_camera_frame* out);

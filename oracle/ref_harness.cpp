@@ -17,6 +17,7 @@
 #include <hip/amd_detail/host_defines.h>
 
 #include <cfloat>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <iostream>
@@ -151,6 +152,36 @@ void ref_intersect(void* h, int n_rays, const float* o, const float* d, float t_
             for (int k = 0; k < 3; k++) { o_.p[k] = si.p[k]; o_.n[k] = si.n[k]; o_.bsdf[k] = si.bsdf[k]; o_.Le[k] = si.Le[k]; }
         }
     }
+}
+
+// Layout and constants of rendering/render_config.h as the reference's own compiler pass sees them (the header comes in
+// through triangle.h:7).  out: sizeof(PrecomputedCDF), offsetof pdf / row_sums / marginal_cdf / row_cdfs / total_weight /
+// is_valid, GRID_RES, GRID_SIZE, GRID_HALF_RES, the five SamplingMode values, BLOCK_X, BLOCK_Y, and the sizes of the
+// records SURVEY 2 quotes (Primitive, BVHNode, SurfaceInteractionRecord, Scene).  22 ints.
+void ref_layout(int* out) {
+    int k = 0;
+    out[k++] = (int)sizeof(PrecomputedCDF);
+    out[k++] = (int)offsetof(PrecomputedCDF, pdf);
+    out[k++] = (int)offsetof(PrecomputedCDF, row_sums);
+    out[k++] = (int)offsetof(PrecomputedCDF, marginal_cdf);
+    out[k++] = (int)offsetof(PrecomputedCDF, row_cdfs);
+    out[k++] = (int)offsetof(PrecomputedCDF, total_weight);
+    out[k++] = (int)offsetof(PrecomputedCDF, is_valid);
+    out[k++] = GRID_RES; out[k++] = GRID_SIZE; out[k++] = GRID_HALF_RES;
+    out[k++] = (int)SamplingMode::SAMPLING_BSDF; out[k++] = (int)SamplingMode::SAMPLING_FORMFACTOR;
+    out[k++] = (int)SamplingMode::SAMPLING_RADIOSITY; out[k++] = (int)SamplingMode::SAMPLING_MIS;
+    out[k++] = (int)SamplingMode::SAMPLING_TOPK;
+    out[k++] = BLOCK_X; out[k++] = BLOCK_Y;
+    out[k++] = (int)sizeof(Primitive); out[k++] = (int)sizeof(BVHNode);
+    out[k++] = (int)sizeof(SurfaceInteractionRecord); out[k++] = (int)sizeof(Scene);
+    out[k++] = (int)sizeof(GRID_D_THETA);          // 8: M_PI is the double one, so the macro is a double expression
+}
+// The grid-step macros (render_config.h:14-17) evaluated by the reference's compiler pass, as doubles:
+// GRID_INV_RES, GRID_INV_HALF_RES, GRID_D_THETA, GRID_D_PHI, M_PI, M_PI * 0.5f (the factor of grid.h:166, 268).
+void ref_grid_constants(double* out) {
+    out[0] = (double)GRID_INV_RES; out[1] = (double)GRID_INV_HALF_RES;
+    out[2] = (double)GRID_D_THETA; out[3] = (double)GRID_D_PHI;
+    out[4] = (double)M_PI; out[5] = (double)(M_PI * 0.5f);
 }
 
 }  // extern "C"

@@ -25,9 +25,10 @@ CASES = [  # scene, subdivision, convert_quads, W, H, spp, max_depth
     ("cbox.obj", 0, False, 64, 64, 16, 8),
     ("cbox_quads.obj", 0, False, 96, 54, 16, 5),
     ("cbox_quads.obj", 0, True, 64, 64, 8, 5),
+    ("cbox.obj", 0, False, 256, 256, 16, 4),          # BASELINE.json configs[0] (C1) at its stated size
 ]
 
-for scene, sub, conv, W, H, spp, depth in CASES:
+for scene, sub, conv, W, H, spp, depth in CASES if "--solver-only" not in sys.argv else []:
     o = OracleScene.load(os.path.join(SCENES, scene), sub, conv)
     rgb, rad, st = o.render(default_camera(), W, H, spp, max_depth=depth)
     name = f"frame_{scene.split('.')[0]}_s{sub}c{int(conv)}_{W}x{H}_{spp}spp_d{depth}.npz"

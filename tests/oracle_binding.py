@@ -125,6 +125,8 @@ def oracle_lib():
         L.po_direction_to_grid_index.argtypes = [C.c_void_p, C.c_void_p]
         L.po_visibility_blocked.restype = C.c_int
         L.po_visibility_blocked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.po_cdf_layout.argtypes = [C.c_void_p]; L.po_cdf_layout.restype = None
+        L.po_grid_constants.argtypes = [C.c_void_p]; L.po_grid_constants.restype = None
         _oracle = L
     return _oracle
 
@@ -323,6 +325,8 @@ def ref_lib():
         L.ref_sample_uniform.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.ref_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                     C.c_int, C.c_void_p]
+        L.ref_layout.argtypes = [C.c_void_p]; L.ref_layout.restype = None
+        L.ref_grid_constants.argtypes = [C.c_void_p]; L.ref_grid_constants.restype = None
         _ref = L
     return _ref
 

@@ -39,6 +39,23 @@ def check_rows_against_oracle(o, rad, rgb, W, H, spp, depth, y0, y1):
     return ost
 
 
+def test_config1_cbox_256_16spp_depth4_whole_frame(R):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case, at its stated size, HIP vs oracle bit for bit (whole
+    frame, workload counters) + the survey's mean-radiance figure (0.186291, placeholder RNG there: 3-sigma tolerance)."""
+    W = H = 256; spp, depth = 16, 4
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path); R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, segments_per_launch=0, collect_stats=True)
+    st = R.render_frame()
+    rgb, rad = R.read_image()
+    ost = check_rows_against_oracle(OracleScene.load(path), rad, rgb, W, H, spp, depth, 0, H)
+    assert (st.samples, st.rays, st.node_visits, st.prim_tests, st.hits) == \
+           (ost.samples, ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+    assert st.samples == W * H * spp
+    assert abs(float(rad.mean(dtype=np.float64)) - 0.186291) < 3.0e-3
+    R.set_config(collect_stats=False)
+
+
 def test_config2_cbox_1024_256spp_depth8_whole_frame(R):
     W = H = 1024; spp, depth = 256, 8
     path = os.path.join(SCENES, "cbox.obj")

@@ -200,3 +200,27 @@ def test_radiosity_prepass_primitive_helpers_bit_exact(pairs):
             for r1, r2 in us:
                 ref_p = np.zeros(3, F); L.ref_sample_uniform(r.h, i, float(r1), float(r2), ref_p.ctypes.data)
                 assert (bits(o.sample_uniform(i, r1, r2)) == bits(ref_p)).all(), (name, i, r1, r2)
+
+
+def test_render_config_layout_and_constants():
+    """rendering/render_config.h as the reference's own compiler pass sees it (it reaches ref_harness.cpp through
+    triangle.h:7): sizeof / field offsets of PrecomputedCDF (:24-31), GRID_* (:7-9), the SamplingMode values (:38-44), the
+    launch block (:51-52) and the grid-step macros (:14-17, doubles because M_PI is the double one) - against the oracle's
+    restatement AND the product's record layout (ptmi_host_cdf_record_layout = csrc/device_scene.h kCdf*)."""
+    import ctypes as C
+    from oracle_binding import oracle_lib
+    import ptmi
+    ref = np.zeros(22, np.int32); ref_lib().ref_layout(ref.ctypes.data)
+    assert ref[:7].tolist() == [2120, 0, 1024, 1056, 1088, 2112, 2116]          # SURVEY 2: "PrecomputedCDF 2120 B"
+    assert ref[7:10].tolist() == [16, 256, 8]
+    assert ref[10:15].tolist() == [0, 1, 2, 3, 4]                                # ptmi_config.sampling_mode values
+    assert ref[15:17].tolist() == [16, 16]
+    assert ref[17:20].tolist() == [4364, 36, 96]                                 # SURVEY 2: Primitive, BVHNode, SurfaceInteractionRecord
+    assert ref[21] == 8                                                          # GRID_D_THETA is a double expression
+    orc = np.zeros(10, np.int32); oracle_lib().po_cdf_layout(orc.ctypes.data)
+    assert orc.tolist() == ref[:10].tolist()
+    assert ptmi.host_cdf_record_layout().tolist() == ref[:10].tolist()
+    rc = np.zeros(6, np.float64); ref_lib().ref_grid_constants(rc.ctypes.data)
+    oc = np.zeros(6, np.float64); oracle_lib().po_grid_constants(oc.ctypes.data)
+    assert (rc.view(np.uint64) == oc.view(np.uint64)).all(), (rc, oc)
+    assert rc[4] == np.pi                                                        # M_PI: the double constant, not math_utils.h's float
