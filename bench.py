@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the per-pixel render loop on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c5tile|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one renderFrame(): all spp samples of every pixel of the frame (scene, path state and RNG
-streams resident in HBM; successive steps are successive frames, RNG state carrying over as in the reference).
+A "step" is one renderFrame(): all spp samples of every pixel of the frame (scene, path state and RNG streams resident
+in HBM; successive steps are successive frames, RNG state carrying over as in the reference, integrator.h:379).
 
-N = 1 : BASELINE.json configs[1] — cbox.obj, 1024x1024, 256 spp, max 8 bounces.
-N > 1 : weak scaling — the same view and spp at side = round(1024*sqrt(N)) pixels, so every GPU owns
-        ~1024^2 pixels; rows are dealt to ranks in interleaved 8-row blocks (no data-path collective),
-        and ONE RCCL gather over xGMI at frame end brings the tiles to rank 0 (inside the timed region).
+Workloads (BASELINE.json `configs`):
+  c2      configs[1]  cbox.obj 1024x1024, 256 spp, max 8 bounces          - the configuration the metric is quoted on (default)
+  c3      configs[2]  cbox_quads.obj 1920x1080, 1024 spp, max 5 bounces
+  c5tile  configs[4]  ONE GPU's share (rank 3 of 8, interleaved 8-row blocks) of the 1,048,576-triangle 2048x2048 frame,
+                      at 64 of its 2048 spp (the rate does not depend on spp): the HBM-relevant workload of this path
+  c4      configs[3]  cbox.obj 4096x4096, 512 spp, max 5 bounces, rows tiled over the N GPUs (strong scaling)
+  c5      configs[4]  the whole 1 M-triangle frame tiled over the N GPUs (strong scaling)
+N = 1 default: c2 as the headline line + `extra_configs` (c3, c5tile), each with its own roofline block.
+N > 1 default: weak scaling of c2 - the same view and spp at side = round(1024*sqrt(N)), so every GPU owns ~1024^2
+pixels; rows are dealt to ranks in interleaved row blocks (no data-path collective) and ONE RCCL gather at frame end
+(ptmi_gather_frame: ncclSend/ncclRecv behind the C ABI, exact tile sizes, 8-bit image) inside the timed region.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel ptmi_bounce, HIP-event timed inside the
-library on its own stream) and `cpu_baseline` (the oracle, timed on the host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library on the streams it
+launches on) and `cpu_baseline` (the oracle, timed on the host cores on a bounded sample).
 """
 import argparse
 import json
@@ -30,15 +37,45 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import ptmi  # noqa: E402
+import ptmi_buildinfo  # noqa: E402
 import ptmi_dist  # noqa: E402
+import ptmi_scenes  # noqa: E402
 
-SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
-SPP, MAX_DEPTH, BASE_SIDE, ROW_BLOCK = 256, 8, 1024, 2   # 2-row blocks: every rank gets exactly side/N rows at N = 1, 2, 4, 8
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9             # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+PROFILE_ROUND = "r02"
+
+CONFIGS = {
+    "c2": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce",
+               served_from="lds", what="BASELINE configs[1]"),
+    "c3": dict(scene="cbox_quads.obj", width=1920, height=1080, spp=1024, max_depth=5, tiling=None, kernel="ptmi_bounce",
+               served_from="lds", what="BASELINE configs[2]"),
+    "c5tile": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_phased",
+                   served_from="l2/mall/hbm", what="BASELINE configs[4], one GPU's share (rank 3 of 8) at 64 of 2048 spp"),
+    "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
+               served_from="lds", what="BASELINE configs[3]"),
+    "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
+               served_from="l2/mall/hbm", what="BASELINE configs[4]"),
+}
+
+
+def tess1m():
+    base = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj")).prims()
+    sc = ptmi_scenes.tessellated_cornell(base, 256, 128, seed=1)          # 16 quads x 256 x 128 cells x 2 triangles
+    return (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
+
+
+def load_scene(r, name):
+    if name == "tess1m":
+        r.load_scene_arrays(*tess1m())
+    else:
+        r.load_scene(os.path.join(SCENES, name))
 
 
 def algorithmic_bytes_per_sample(st, quads):
-    """SURVEY.md §8(d): rays/sample * (144 + 32*nodes/ray + 36|48*tests/ray + 36*hit_rate) + 24."""
+    """SURVEY.md 8(d): rays/sample * (144 + 32*nodes/ray + 36|48*tests/ray + 36*hit_rate) + 24."""
     rays_per_sample = st.rays / st.samples
     return rays_per_sample * (144.0 + 32.0 * st.node_visits / st.rays + (48.0 if quads else 36.0) * st.prim_tests / st.rays
                               + 36.0 * st.hits / st.rays) + 24.0
@@ -67,18 +104,128 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(side, target_seconds=12.0):
-    """The oracle (CPU restatement, kind "port") on all host cores, same scene/camera/depth, reduced spp."""
+def cpu_baseline(cfg, width, height, target_seconds=12.0):
+    """The oracle (CPU restatement, kind "port") on all host cores, same scene/camera/depth, bounded sample: full frame at
+    reduced spp for the Cornell scenes, a band of rows for the 1 M-triangle scene."""
     from oracle_binding import OracleScene, default_camera
-    o = OracleScene.load(SCENE)
     cores = host_cores()
-    _, _, st = o.render(default_camera(), side, side, 2, max_depth=MAX_DEPTH, n_threads=cores)      # calibrate
+    if cfg["scene"] == "tess1m":
+        o = OracleScene.from_arrays(*tess1m())
+        y0, y1 = height // 2, height // 2 + 8
+    else:
+        o = OracleScene.load(os.path.join(SCENES, cfg["scene"]))
+        y0, y1 = 0, height
+    depth = cfg["max_depth"]
+    _, _, st = o.render(default_camera(), width, height, 2, max_depth=depth, n_threads=cores, y0=y0, y1=y1)      # calibrate
     rate = st.samples / max(st.seconds, 1e-9)
-    spp = int(max(2, min(SPP, round(target_seconds * rate / (side * side)))))
-    _, _, st = o.render(default_camera(), side, side, spp, max_depth=MAX_DEPTH, n_threads=cores)
+    spp = int(max(2, min(cfg["spp"], round(target_seconds * rate / (width * (y1 - y0))))))
+    _, _, st = o.render(default_camera(), width, height, spp, max_depth=depth, n_threads=cores, y0=y0, y1=y1)
     return {"value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"cbox.obj {side}x{side}, {spp} of {SPP} spp, max_depth {MAX_DEPTH}, "
+            "sample": f"{cfg['scene']} {width}x{height} rows {y0}:{y1}, {spp} of {cfg['spp']} spp, max_depth {depth}, "
                       f"{st.samples / 1e6:.1f} Msamples in {st.seconds:.1f} s (oracle/ptmi_oracle.c, OpenMP over rows)"}
+
+
+def load_profile(name):
+    """profiles/<round>_pmc_<config>.json (tools/profile.sh + tools/pmc_summary.py), or (None, why)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{name}.json")
+    if not os.path.exists(path):
+        return None, "no committed profile"
+    try:
+        prof = json.load(open(path))
+    except Exception as e:
+        return None, f"unreadable profile: {e}"
+    ok, how = ptmi_buildinfo.profile_is_current(prof)
+    if not ok:
+        return None, "profile_stale"
+    prof["_matched"] = how
+    prof["_path"] = os.path.relpath(path, ROOT)
+    return prof, None
+
+
+def roofline_block(name, cfg, m, exact_workload):
+    """roofline of the dominant kernel of one measured workload `m` (see measure())."""
+    kernel_s = m["kernel_ms"] * 1e-3
+    launches = max(m["launches"], 1)
+    steps = m["steps"]
+    step_s = m["elapsed"] / steps
+    prof, why = load_profile(name) if exact_workload else (None, "workload differs from the profiled one")
+    # what this design sends to memory by construction: every queued pixel reads and writes its 88-byte state once per
+    # launch (+ 4-byte queue entries in and out) - counted live by the library (ptmi_stats.path_visits)
+    state_bytes_per_step = m["visits"] * (88 + 88 + 4 + 4) / steps
+    alg_bytes_per_step = m["local_samples_per_step"] * m["bytes_per_sample"]
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": cfg["kernel"],
+           "launches_per_step": round(launches / steps, 1), "avg_launch_ms": round(m["kernel_ms"] / launches, 4),
+           "concurrent_streams": m["streams"],
+           "summed_launch_time_over_frame_time": round(kernel_s / max(m["frame_dev_s"], 1e-12), 4)}
+    if prof:
+        hbm_bytes_per_step = prof["hbm_bytes_per_frame"]
+        out["traffic"] = round(prof["hbm_bytes_per_launch"], 1)          # 2 x FETCH_SIZE + WRITE_SIZE, per launch (guide: gfx950 rule)
+        out["achieved_source"] = f"rocprofv3 PMC ({prof['_path']}, stamp matched by {prof['_matched']})"
+        out["profile_stale"] = False
+    else:
+        hbm_bytes_per_step = state_bytes_per_step
+        out["traffic"] = None
+        out["achieved_source"] = f"path-state byte model, live launch counts ({why})"
+        out["profile_stale"] = why == "profile_stale"
+    achieved = hbm_bytes_per_step / step_s / 1e9
+    out["achieved"] = round(achieved, 1)
+    out["frac"] = round(min(achieved / HBM_PEAK_GBS, 1.0), 4)
+    assert 0.0 < out["frac"] <= 1.0, out
+    # SURVEY 8(d)'s algorithmic figure: NOT compared with the HBM peak when the scene is LDS-resident
+    out["algorithmic_bytes_per_sample"] = round(m["bytes_per_sample"], 1)
+    out["algorithmic_bytes_per_launch"] = round(alg_bytes_per_step * steps / launches, 1)
+    out["algorithmic_GBps"] = round(alg_bytes_per_step / step_s / 1e9, 1)
+    out["algorithmic_GBps_per_launch"] = round(alg_bytes_per_step * steps / max(kernel_s, 1e-12) / 1e9, 1)
+    out["served_from"] = cfg["served_from"]
+    out["path_state_bytes_per_launch"] = round(state_bytes_per_step * steps / launches, 1)
+    out["path_state_GBps"] = round(state_bytes_per_step / step_s / 1e9, 1)
+    if prof:
+        if prof.get("fabric_read_bytes_per_frame") is not None:
+            # FETCH_SIZE counts L2 -> fabric requests; Infinity-Cache hits are included, so this bounds HBM reads from above
+            out["fabric_read_GBps"] = round(prof["fabric_read_bytes_per_frame"] / step_s / 1e9, 1)
+            out["hbm_write_GBps"] = round(prof["hbm_write_bytes_per_frame"] / step_s / 1e9, 1)
+        for k in ("tcc_hit_rate", "valu_lane_utilisation", "wait_frac"):
+            if prof.get(k) is not None:
+                out[k] = prof[k]
+        insts = prof.get("valu_wave_insts_per_frame")
+        if insts:
+            per_simd_per_s = insts / max(m["frame_dev_s"] / steps, 1e-12) / N_SIMD
+            clk = CLOCK_HZ / per_simd_per_s
+            out["valu"] = {"wave_insts_per_step": insts, "insts_per_simd_per_s": round(per_simd_per_s, 1),
+                           "clocks_per_inst_at_2p4GHz": round(clk, 3),
+                           # guide: a wave64 VALU instruction issues over 2 cycles -> 1.2e9 per SIMD per second at 2.4 GHz
+                           "issue_frac_guide_2clk": round(2.0 / clk, 4),
+                           # this repo's microbenchmark (tools/valu_rate*.hip): 2.4 clocks for an all-full-rate stream
+                           "issue_frac_measured_floor_2p4clk": round(2.4 / clk, 4)}
+    out["note"] = ("achieved = HBM bytes per step / step time, frac <= 1 by construction; algorithmic_* follow SURVEY 8(d) and count "
+                   "node/triangle/material reads, which are served from " + cfg["served_from"])
+    return out
+
+
+def measure(r, cfg, steps, warmup, step_fn, barrier, segments, reduce_max):
+    """counters frame (untimed, stats build) + warmup + `steps` timed frames of the loaded workload"""
+    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False)
+    st_counts = r.render_frame()
+    quads = r.scene_info()["n_quads"] > 0
+    bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
+    r.set_config(collect_stats=False)
+    for _ in range(warmup):
+        step_fn(False)
+    kernel_ms = 0.0; launches = 0; visits = 0; frame_dev_s = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = step_fn(True)
+        kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; visits += st.path_visits; frame_dev_s += st.seconds
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    n_local_px = len(r.local_rows()) * r.width
+    return dict(elapsed=elapsed, steps=steps, kernel_ms=kernel_ms, launches=launches, visits=visits, frame_dev_s=frame_dev_s,
+                bytes_per_sample=bytes_per_sample, local_samples_per_step=float(n_local_px) * cfg["spp"],
+                streams=r.config.streams or (2 if n_local_px >= (1 << 18) else 1),
+                counters=dict(rays_per_sample=round(st_counts.rays / st_counts.samples, 3),
+                              nodes_per_ray=round(st_counts.node_visits / st_counts.rays, 2),
+                              tests_per_ray=round(st_counts.prim_tests / st_counts.rays, 2)))
 
 
 def main():
@@ -86,14 +233,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)          # for quick experiments only
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1, config c2: skip the extra_configs (c3, c5tile)")
+    ap.add_argument("--spp", type=int, default=0, help=argparse.SUPPRESS)          # for quick experiments only
     ap.add_argument("--side", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--gather", choices=("rgb8", "radiance", "both"), default="rgb8", help="what the frame-end gather moves (N > 1)")
+    # profile pass (tools/profile.sh): exactly `steps` frames of the timing build of the kernel, nothing else on the GPU
+    ap.add_argument("--profile-pass", action="store_true", help=argparse.SUPPRESS)
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: ranks share devices and the gather
     # goes through host memory with gloo.  Never used for reported numbers.
     ap.add_argument("--rehearse-gloo", action="store_true", help=argparse.SUPPRESS)
-    # exercise the RCCL code path (init, gather, barrier) even with one rank; never used for reported numbers
+    # exercise the RCCL code path (comm init, gather, barrier) even with one rank; never used for reported numbers
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -120,141 +272,131 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
 
-    side = args.side or int(round(BASE_SIDE * math.sqrt(n_gpus)))
-    spp = args.spp
+    name = args.config
+    cfg = dict(CONFIGS[name])
+    strong = name in ("c4", "c5")
+    if name == "c2" and world > 1:                    # weak scaling of the headline configuration
+        cfg["width"] = cfg["height"] = int(round(1024 * math.sqrt(n_gpus)))
+    if args.side:
+        cfg["width"] = cfg["height"] = args.side
+    if args.spp:
+        cfg["spp"] = args.spp
+    exact = not args.side and not args.spp and not args.segments and world == 1
+    row_block = 2 if name == "c2" else 8             # 2-row blocks: every rank gets exactly side/N rows at N = 1, 2, 4, 8
 
     r = ptmi.Renderer(device_index)
-    r.load_scene(SCENE)
-    quads = r.scene_info()["n_quads"] > 0
+    load_scene(r, cfg["scene"])
 
-    def allocate():
-        r.update_resolution(side, side, n_ranks=world, rank=rank, row_block=ROW_BLOCK)   # re-seeds the RNG streams
+    def allocate(c):
+        if c["tiling"] and world == 1:
+            n_r, rk, rb = c["tiling"]
+            r.update_resolution(c["width"], c["height"], n_ranks=n_r, rank=rk, row_block=rb)      # re-seeds the RNG streams
+        else:
+            r.update_resolution(c["width"], c["height"], n_ranks=world, rank=rank, row_block=row_block)
 
-    allocate()
-    rows = r.local_rows()
-    n_local_rows = len(rows)
-
-    # gather plumbing (torch = device memory + RCCL only)
-    dev = torch.device("cuda", device_index)
-    fg = ptmi_dist.FrameGather(dist, side, side, world, rank, ROW_BLOCK, torch.device("cpu") if args.rehearse_gloo else dev, n_send=2)
-    assert fg.n_local == n_local_rows
-    slot_free = [None, None]                         # per send buffer: event after the gather that reads it
-    frame_no = [0]
+    allocate(cfg)
+    what = {"rgb8": 1, "radiance": 2, "both": 3}[args.gather]
+    rccl = use_dist and not args.rehearse_gloo
+    fg = None
+    if rccl:
+        ptmi_dist.dist_init_from_torch(r, dist)       # ships the ncclUniqueId through the torch process group
+    elif use_dist:
+        fg = ptmi_dist.FrameGather(dist, cfg["width"], cfg["height"], world, rank, row_block, torch.device("cpu"))
 
     def step(stats):
-        # Frames are independent, so the exchange of frame k overlaps the rendering of frame k + 1: the RCCL gather and
-        # the row placement on rank 0 are only ENQUEUED here (torch's stream); the next render_frame runs on the
-        # library's own streams meanwhile.  A send buffer is reused two frames later, after its gather's event.
-        # Everything outstanding is drained by barrier() (torch.cuda.synchronize) before the clock stops.
+        # Frames are independent, so the exchange of frame k overlaps the rendering of frame k + 1: ptmi_gather_frame only
+        # ENQUEUES the RCCL sends/receives and the row placement (library-owned stream); the next render_frame runs
+        # meanwhile and its resolve pass waits on the device for the gather that still reads the tile.
+        # Everything outstanding is drained by barrier() before the clock stops.
         st = r.render_frame(want_stats=stats)
-        if use_dist:
-            slot = frame_no[0] & 1
-            frame_no[0] += 1
-            if args.rehearse_gloo:
-                rgb, rad = r.read_image()
-                fg.sends_rgb[slot][:n_local_rows] = torch.from_numpy(rgb); fg.sends_rad[slot][:n_local_rows] = torch.from_numpy(rad)
-                fg.gather(slot)
-            else:
-                if slot_free[slot] is not None:
-                    slot_free[slot].synchronize()
-                r.copy_image_device(fg.sends_rgb[slot].data_ptr(), fg.sends_rad[slot].data_ptr())
-                fg.gather(slot)                      # the single RCCL exchange of a frame
-                ev = torch.cuda.Event(); ev.record()
-                slot_free[slot] = ev
+        if rccl:
+            r.gather_frame(0, what)                   # the single exchange of a frame
+        elif use_dist:
+            rgb, rad = r.read_image()
+            n = len(rgb)
+            fg.send_rgb[:n] = torch.from_numpy(rgb); fg.send_rad[:n] = torch.from_numpy(rad)
+            fg.gather()
         return st
 
     def barrier():
+        if rccl:
+            r.gather_wait()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: deterministic workload counters for the roofline model (stats build of the kernel)
-    r.set_config(spp=spp, max_depth=MAX_DEPTH, segments_per_launch=args.segments, collect_stats=True)
-    st_counts = r.render_frame()
-    bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
-
-    # Successive steps are successive frames: as in the reference, the RNG streams carry over from frame to
-    # frame (integrator.h:379), so every step is statistically the same work on fresh samples.
-    r.set_config(collect_stats=False)
-    for _ in range(args.warmup):
-        step(False)
-
-    kernel_ms = 0.0
-    launches = 0
-    visits = 0
-    frame_dev_s = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step(True)
-        kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; visits += st.path_visits; frame_dev_s += st.seconds
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_gloo else dev)
+    def reduce_max(elapsed):
+        if not use_dist:
+            return elapsed
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_gloo else torch.device("cuda", device_index))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    total_samples = float(side) * side * spp * args.steps
-    value = total_samples / elapsed / 1e6
-    # roofline of the dominant kernel on THIS rank: algorithmic bytes of its launches / their summed duration
-    local_samples = float(n_local_rows) * side * spp * args.steps
-    achieved = local_samples * bytes_per_sample / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes; see profiles/README.md)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_bounce.json")
-    if world == 1 and os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # The limiter this kernel actually runs into: vector-ALU issue.  VALU wave-instructions per frame are a constant of
-    # the workload (deterministic; SQ_INSTS_VALU of the committed PMC profile, one frame of exactly this configuration);
-    # a SIMD issues at most one per 2.4 clocks for a full-rate stream (tools/valu_rate*.hip), 4 SIMDs x 256 CUs.
-    valu = None
-    pmc_sq = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if world == 1 and side == BASE_SIDE and spp == SPP and os.path.exists(pmc_sq):
-        try:
-            insts = json.load(open(pmc_sq))["ptmi_bounce"]["SQ_INSTS_VALU"]["sum"]
-            per_simd_per_s = insts * args.steps / max(frame_dev_s, 1e-12) / 1024.0
-            valu = {"wave_insts_per_step": insts, "insts_per_simd_per_s": round(per_simd_per_s, 1),
-                    "clocks_per_inst_at_2p4GHz": round(2.4e9 / per_simd_per_s, 3), "full_rate_floor_clocks": 2.4,
-                    "issue_frac": round(2.4 / (2.4e9 / per_simd_per_s), 4)}
-        except Exception:
-            valu = None
-    # what this design can send to HBM at all: every queued pixel reads and writes its 88-byte state once per
-    # launch (+ 4-byte queue entries); nodes/triangles/materials are LDS-resident for this scene
-    state_bytes = visits * (88 + 88 + 4 + 4)
+    if args.profile_pass:
+        r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=args.segments, collect_stats=False)
+        for _ in range(args.steps):
+            r.render_frame(want_stats=False)
+        print(json.dumps({"profile_pass": name, "frames": args.steps, **ptmi_buildinfo.stamps()}), flush=True)
+        r.close()
+        return
+
+    m = measure(r, cfg, args.steps, args.warmup, step, barrier, args.segments, reduce_max)
+    total_samples = float(cfg["width"]) * cfg["height"] * cfg["spp"] * args.steps if not (cfg["tiling"] and world == 1) \
+        else m["local_samples_per_step"] * args.steps
+    value = total_samples / m["elapsed"] / 1e6
+
+    # the reference's renderFrame() ends with the D2H of the 8-bit image (application.h:211): same steps again with
+    # config.download_image (pinned host image); reported next to `value`, which leaves results on the device
+    value_incl_d2h = None
+    if world == 1 and not use_dist:
+        r.set_config(download_image=True)
+        for _ in range(min(args.warmup, 1)):
+            r.render_frame(want_stats=False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.render_frame(want_stats=False)
+        barrier()
+        value_incl_d2h = total_samples / (time.perf_counter() - t0) / 1e6
+        r.set_config(download_image=False)
+
+    out = None
     if rank == 0:
+        tiled = f", rank {cfg['tiling'][1]} of {cfg['tiling'][0]} (interleaved {cfg['tiling'][2]}-row blocks)" if cfg["tiling"] and world == 1 else ""
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cbox.obj {side}x{side}, {spp} spp, max_depth {MAX_DEPTH}, Cornell-box scene fixture, "
-                                   f"default camera, seed 2023" + ("" if world == 1 else f", {world} GPUs x ~{BASE_SIDE}^2 px, interleaved {ROW_BLOCK}-row blocks + 1 RCCL gather"),
-                       "width": side, "height": side, "spp": spp, "max_depth": MAX_DEPTH,
-                       "segments_per_launch": args.segments or "default", "parallelism": f"tile{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ptmi_bounce", "launches_per_step": launches / max(args.steps, 1),
-                         "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                         "algorithmic_bytes_per_launch": round(local_samples * bytes_per_sample / max(launches, 1), 1),
-                         # two pixel chunks run through two HIP streams: launches overlap pairwise, so the summed launch
-                         # time exceeds the frame time; achieved_chip divides the same bytes by the frame's device time
-                         "concurrent_streams": r.config.streams or (2 if n_local_rows * side >= (1 << 18) else 1),
-                         "summed_launch_time_over_frame_time": round(kernel_ms * 1e-3 / max(frame_dev_s, 1e-12), 4),
-                         "achieved_chip": round(local_samples * bytes_per_sample / max(frame_dev_s, 1e-12) / 1e9, 1),
-                         "path_state_bytes_per_launch": round(state_bytes / max(launches, 1), 1),
-                         "path_state_GBps": round(state_bytes / max(kernel_ms * 1e-3, 1e-12) / 1e9, 1),
-                         "valu": valu,
-                         "note": "algorithmic bytes follow SURVEY 8(d) and count node/triangle/material reads as memory "
-                                 "traffic; for this 32-triangle scene they are served from LDS, so the kernel is VALU-issue-bound "
-                                 "and only the path-state share (path_state_*) can reach HBM"},
+            "warmup": args.warmup, "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {cfg['scene']} {cfg['width']}x{cfg['height']}, {cfg['spp']} spp, max_depth {cfg['max_depth']}{tiled}, "
+                                   f"default camera, seed 2023 ({cfg['what']})" +
+                                   ("" if world == 1 else f", {world} GPUs, interleaved {row_block}-row blocks + 1 RCCL gather ({args.gather}) per frame"),
+                       "name": name, "width": cfg["width"], "height": cfg["height"], "spp": cfg["spp"], "max_depth": cfg["max_depth"],
+                       "segments_per_launch": args.segments or "default", "parallelism": f"tile{world}", **m["counters"]},
+            "roofline": roofline_block(name, cfg, m, exact),
         }
+        if value_incl_d2h is not None:
+            out["value_incl_d2h"] = round(value_incl_d2h, 3)
+            out["d2h_note"] = "value leaves the frame on the device; value_incl_d2h adds renderFrame()'s 3 B/pixel copy to pinned host memory (application.h:211)"
+
+    # N = 1, headline configuration: the other single-GPU workloads of BASELINE.json, driver-timed in the same run
+    if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
+        extras = []
+        for xname, xsteps in (("c3", 2), ("c5tile", 3)):
+            xcfg = dict(CONFIGS[xname])
+            load_scene(r, xcfg["scene"])
+            allocate(xcfg)
+            xm = measure(r, xcfg, xsteps, 1, step, barrier, 0, reduce_max)
+            xsamples = xm["local_samples_per_step"] * xsteps
+            tiled = f", rank {xcfg['tiling'][1]} of {xcfg['tiling'][0]}" if xcfg["tiling"] else ""
+            extras.append({"name": xname, "workload": f"{xcfg['scene']} {xcfg['width']}x{xcfg['height']}, {xcfg['spp']} spp, max_depth {xcfg['max_depth']}{tiled} ({xcfg['what']})",
+                           "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "steps": xsteps, "warmup": 1,
+                           "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"],
+                           "roofline": roofline_block(xname, xcfg, xm, True)})
+        out["extra_configs"] = extras
+
+    if rank == 0:
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(side)
+            out["cpu_baseline"] = cpu_baseline(cfg, cfg["width"], cfg["height"])
         print(json.dumps(out), flush=True)
     r.close()
     if use_dist:

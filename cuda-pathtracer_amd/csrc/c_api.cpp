@@ -27,6 +27,7 @@ int guarded(Fn&& fn) {
     }
     catch (const IoError& e) { g_last_error = e.what(); return PTMI_E_IO; }
     catch (const ArgError& e) { g_last_error = e.what(); return PTMI_E_INVALID; }
+    catch (const DistError& e) { g_last_error = e.what(); return PTMI_E_DIST; }
     catch (const std::bad_alloc&) { g_last_error = "host allocation failed"; return PTMI_E_NOMEM; }
     catch (const std::exception& e) { g_last_error = e.what(); return PTMI_E_INVALID; }
     catch (...) { g_last_error = "unknown error"; return PTMI_E_INVALID; }
@@ -68,6 +69,7 @@ void ptmi_default_config(ptmi_config* c) {
     const AppConfig d;
     c->spp = d.spp; c->max_depth = d.max_depth; c->sampling_mode = (int)d.sampling_mode; c->seed_base = d.seed_base;
     c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0; c->streams = 0; c->mis_bsdf_fraction = d.mis_bsdf_fraction; c->integrator = 0;
+    c->download_image = 0;
 }
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
@@ -372,14 +374,15 @@ int ptmi_set_config(ptmi_ctx* c, const ptmi_config* cfg) {
         need(cfg->mis_bsdf_fraction >= 0.0f && cfg->mis_bsdf_fraction <= 1.0f, "mis_bsdf_fraction must be in [0, 1]");
         need(cfg->integrator == 0 || cfg->integrator == 1, "integrator must be 0 (PathTracing) or 1 (Radiosity)");
         need(cfg->segments_per_launch >= 0, "segments_per_launch must be >= 0");
-        AppConfig& a = c->app.config;
+        need(cfg->streams >= 0 && cfg->streams <= RenderState::kMaxChunks, "streams must be 0..4");
+        AppConfig& a = c->app.config;                    // every check is above this line: a rejected config changes nothing
         a.spp = cfg->spp; a.max_depth = cfg->max_depth; a.sampling_mode = (SamplingMode)cfg->sampling_mode;
         a.mis_bsdf_fraction = cfg->mis_bsdf_fraction;
         a.current_integrator = cfg->integrator ? IntegratorType::Radiosity : IntegratorType::PathTracing;
         a.seed_base = cfg->seed_base; a.segments_per_launch = cfg->segments_per_launch; a.collect_stats = cfg->collect_stats != 0;
-        need(cfg->streams >= 0 && cfg->streams <= RenderState::kMaxChunks, "streams must be 0..4");
         c->app.render.allow_tile8 = cfg->wave_tiles != 0;
         c->app.render.want_chunks = cfg->streams;
+        c->app.render.download_image = cfg->download_image != 0;
     });
 }
 
@@ -447,6 +450,87 @@ int ptmi_copy_image_device(const ptmi_ctx* c, void* d_rgb8_dst, void* d_radiance
         if (d_rgb8_dst) PTMI_HIP(hipMemcpyAsync(d_rgb8_dst, r.d_image, r.n_local * 3, hipMemcpyDeviceToDevice, r.stream));
         if (d_radiance_dst) PTMI_HIP(hipMemcpyAsync(d_radiance_dst, r.d_radiance, r.n_local * 3 * sizeof(float), hipMemcpyDeviceToDevice, r.stream));
         PTMI_HIP(hipStreamSynchronize(r.stream));
+    });
+}
+
+int ptmi_host_image(const ptmi_ctx* c, const unsigned char** rgb8, uint64_t* n_bytes) {
+    return guarded([&] {
+        need(c && rgb8, "NULL argument");
+        need(c->app.render.h_image != nullptr, "buffers not allocated");
+        *rgb8 = c->app.render.h_image;
+        if (n_bytes) *n_bytes = (uint64_t)c->app.render.n_local * 3;
+    });
+}
+
+// ---- multi-GPU frame exchange (csrc/dist.hip) ----
+int ptmi_dist_unique_id(void* out_id) {
+    return guarded([&] { need(out_id != nullptr, "NULL argument"); distUniqueId(out_id); });
+}
+int ptmi_dist_init(ptmi_ctx* c, const void* id, int n_ranks, int rank) {
+    return guarded([&] {
+        need(c && id, "NULL argument");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.render.resolve_gate = nullptr;
+        c->app.dist.init(id, n_ranks, rank);
+    });
+}
+int ptmi_dist_finalize(ptmi_ctx* c) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.render.resolve_gate = nullptr;
+        c->app.dist.finalize();
+    });
+}
+int ptmi_gather_frame(ptmi_ctx* c, int dst_rank, int what) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        c->app.dist.gatherFrame(c->app.render, dst_rank, what);
+        c->app.render.resolve_gate = c->app.dist.gather_done;
+    });
+}
+int ptmi_gather_wait(ptmi_ctx* c) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); PTMI_HIP(hipSetDevice(c->app.device_id)); c->app.dist.wait(); });
+}
+int ptmi_frame_device(const ptmi_ctx* c, void** d_rgb8, void** d_radiance) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        const DistState& d = c->app.dist;
+        need(d.d_frame_rgb || d.d_frame_rad, "no gathered frame on this rank (ptmi_gather_frame with dst_rank = this rank first)");
+        if (d_rgb8) *d_rgb8 = d.have_rgb ? d.d_frame_rgb : nullptr;
+        if (d_radiance) *d_radiance = d.have_rad ? d.d_frame_rad : nullptr;
+    });
+}
+int ptmi_read_frame(ptmi_ctx* c, unsigned char* rgb8, float* radiance) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        DistState& d = c->app.dist;
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        need(!rgb8 || d.have_rgb, "the 8-bit frame was never gathered to this rank");
+        need(!radiance || d.have_rad, "the radiance frame was never gathered to this rank");
+        d.wait();
+        const size_t n = (size_t)d.frame_w * (size_t)d.frame_h * 3;
+        if (rgb8) PTMI_HIP(hipMemcpy(rgb8, d.d_frame_rgb, n, hipMemcpyDeviceToHost));
+        if (radiance) PTMI_HIP(hipMemcpy(radiance, d.d_frame_rad, n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+int ptmi_dist_barrier(ptmi_ctx* c) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); PTMI_HIP(hipSetDevice(c->app.device_id)); c->app.dist.barrier(); });
+}
+int ptmi_dist_allreduce_max(ptmi_ctx* c, double* value) {
+    return guarded([&] {
+        need(c && value, "NULL argument");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        *value = c->app.dist.allreduceMax(*value);
+    });
+}
+int ptmi_debug_place_tiles(ptmi_ctx* c, int width, int height, int n_ranks, int row_block, const unsigned char* tiles_rgb8,
+                           const float* tiles_radiance, unsigned char* out_rgb8, float* out_radiance) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        debugPlaceTiles(width, height, n_ranks, row_block, tiles_rgb8, tiles_radiance, out_rgb8, out_radiance, c->app.render.stream);
     });
 }
 

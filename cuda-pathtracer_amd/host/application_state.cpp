@@ -416,6 +416,7 @@ void SceneState::chooseTraversal() {
 void RenderState::freeBuffers() {
     void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h_image) { (void)hipHostFree(h_image); h_image = nullptr; }
     for (Chunk& c : chunk) {
         void* cp[] = {c.d_queue_init, c.d_queue[0], c.d_queue[1], c.d_count};
         for (void* p : cp) if (p) (void)hipFree(p);
@@ -443,6 +444,7 @@ void RenderState::allocateBuffers() {
     d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
     d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
     d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
+    PTMI_HIP(hipHostMalloc((void**)&h_image, n * 3));                     // h_image = new unsigned char[img_size], application_state.h:99
     // chunks: 256-slot blocks dealt round-robin, so a workgroup still reads 256 consecutive state records
     n_chunks = want_chunks > 0 ? std::min(want_chunks, (int)kMaxChunks) : (n_local >= (size_t)(1 << 18) ? 2 : 1);
     std::vector<std::vector<int>> slots(n_chunks);
@@ -508,6 +510,8 @@ ApplicationState::ApplicationState(int device) : device_id(device) {
 
 ApplicationState::~ApplicationState() {
     (void)hipSetDevice(device_id);
+    render.resolve_gate = nullptr;
+    dist.finalize();
     for (hipEvent_t ev : event_pool) (void)hipEventDestroy(ev);
     scene.cleanup();
     render.freeBuffers();
@@ -537,6 +541,16 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     const int n_local = (int)r.n_local;
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
     hipStream_t s = r.stream;
+    // whatever way this function is left, nothing of this frame is still in flight (an exception thrown between two
+    // launches must not let the next frame start on top of the chunk streams' queued work)
+    struct Drain {
+        RenderState& r; bool armed = true;
+        ~Drain() {
+            if (!armed) return;
+            for (int c = 0; c < RenderState::kMaxChunks; c++) if (r.chunk[c].stream) (void)hipStreamSynchronize(r.chunk[c].stream);
+            (void)hipStreamSynchronize(r.stream);
+        }
+    } drain{r};
     const bool want_stats = g.config.collect_stats;
 
     auto event = [&](size_t i) {
@@ -549,11 +563,14 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     if (want_stats) PTMI_HIP(hipMemsetAsync(r.d_stats, 0, sizeof(StatCounters), s));
 
     if (g.config.current_integrator == IntegratorType::Radiosity) {       // application.h:193-197
+        if (r.resolve_gate) PTMI_HIP(hipStreamWaitEvent(s, r.resolve_gate, 0));
         launch_render_radiosity(g.scene.d_scene, r.tile, r.d_state, fp, r.d_image, r.d_radiance, s);
         PTMI_HIP(hipGetLastError());
         const hipEvent_t ev_done = event(n_ev++);
         PTMI_HIP(hipEventRecord(ev_done, s));
+        if (r.download_image && n_local) PTMI_HIP(hipMemcpyAsync(r.h_image, r.d_image, (size_t)n_local * 3, hipMemcpyDeviceToHost, s));
         PTMI_HIP(hipStreamSynchronize(s));
+        drain.armed = false;
         if (stats) {
             float ms = 0.0f;
             PTMI_HIP(hipEventElapsedTime(&ms, ev_begin, ev_done));
@@ -622,11 +639,15 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         PTMI_HIP(hipStreamWaitEvent(s, ev, 0));
     }
     const size_t after_pairs = n_ev;
+    if (r.resolve_gate) PTMI_HIP(hipStreamWaitEvent(s, r.resolve_gate, 0));   // a gather of the previous frame may still read the tile
     launch_resolve(r.tile, r.d_state, g.config.spp, r.d_image, r.d_radiance, s);
     const hipEvent_t ev_end = event(n_ev++);
     PTMI_HIP(hipEventRecord(ev_end, s));
+    // cudaMemcpy(h_image, d_image, img_size, DeviceToHost), application.h:211 ("Memory Transfer" stage)
+    if (r.download_image && n_local) PTMI_HIP(hipMemcpyAsync(r.h_image, r.d_image, (size_t)n_local * 3, hipMemcpyDeviceToHost, s));
     PTMI_HIP(hipStreamSynchronize(s));                 // cudaDeviceSynchronize, application.h:199
     PTMI_HIP(hipGetLastError());
+    drain.armed = false;
 
     if (stats) {
         float ms = 0.0f;

@@ -27,6 +27,7 @@ struct HipError : std::runtime_error {
 };
 struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DistError : std::runtime_error { using std::runtime_error::runtime_error; };   // RCCL missing or an nccl* call failed
 
 // cudaMallocSafe (utils/cuda_utils.h:54-60): throws on failure
 void* hipMallocSafe(size_t bytes, const char* name);
@@ -128,6 +129,11 @@ struct RenderState {
     PathState d_state;                               // path state + RNG (replaces d_rand_state)
     unsigned char* d_image = nullptr;                // RGB8, local rows
     float* d_radiance = nullptr;                     // float3 mean radiance, local rows
+    unsigned char* h_image = nullptr;                // RGB8, local rows, PINNED: RenderState::h_image (application_state.h:77, 99);
+                                                     // renderFrame() ends with the D2H into it (application.h:211) when download_image
+    bool download_image = false;
+    hipEvent_t resolve_gate = nullptr;               // not owned: while set, the next resolve waits for it (a frame gather still
+                                                     // reading this rank's tile, csrc/dist.hip)
     // The local pixels are dealt to kMaxChunks independent queues (256-slot blocks, round-robin), each driven through
     // its own stream: while one chunk's launch drains (kernel tail, state write-back burst) the other chunk's
     // workgroups keep the CUs busy.  Chunks share nothing but the read-only scene.
@@ -153,6 +159,38 @@ struct RenderState {
     ~RenderState() { freeBuffers(); }
 };
 
+// Multi-GPU frame exchange (csrc/dist.hip): one RCCL communicator per ctx (one process per GPU), a stream of its own, and
+// on the destination rank the staging + whole-frame buffers.  New in this implementation (the reference is single-GPU).
+struct DistState {
+    void* comm = nullptr;                            // ncclComm_t
+    int n_ranks = 1, rank = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t gather_done = nullptr;
+    bool pending = false;                            // a gather has been enqueued and not waited for
+    int* d_token = nullptr;                          // barrier payload
+    // destination side, (re)allocated per frame geometry
+    unsigned char *d_stage_rgb = nullptr, *d_frame_rgb = nullptr;
+    float *d_stage_rad = nullptr, *d_frame_rad = nullptr;
+    long long* d_tile_offset = nullptr;              // per rank: first element of its tile in the staging buffers
+    std::vector<long long> h_tile_offset;
+    int frame_w = 0, frame_h = 0, frame_row_block = 0, frame_ranks = 0;
+    bool have_rgb = false, have_rad = false;         // what the frame buffers hold
+
+    void init(const void* unique_id128, int n_ranks, int rank);      // ncclCommInitRank
+    void gatherFrame(const struct RenderState& r, int dst_rank, int what /* 1 rgb8 | 2 radiance */);   // enqueues, does not wait
+    void wait();
+    void barrier();                                  // all ranks (1-int all-reduce + stream sync)
+    double allreduceMax(double v);
+    void finalize();
+    ~DistState() { finalize(); }
+private:
+    void ensureFrame(const TileMap& tm, bool want_rgb, bool want_rad);
+    void freeFrame();
+};
+void distUniqueId(void* out128);                     // ncclGetUniqueId
+void debugPlaceTiles(int width, int height, int n_ranks, int row_block, const unsigned char* h_tiles_rgb, const float* h_tiles_rad,
+                     unsigned char* out_rgb, float* out_rad, hipStream_t s);
+
 struct FrameStats {
     double seconds = 0, bounce_kernel_ms = 0;
     uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0;
@@ -163,6 +201,7 @@ struct ApplicationState {
     RenderState render;
     SceneState scene;
     RadiosityState radiosity;
+    DistState dist;
     AppConfig config;
     std::vector<uint32_t> h_jump;                    // 32 x 160 x 5 words
     std::vector<hipEvent_t> event_pool;

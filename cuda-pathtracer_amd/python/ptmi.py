@@ -25,7 +25,9 @@ EXPORTS = [
     "ptmi_debug_intersect", "ptmi_debug_rng", "ptmi_debug_cosine_sample", "ptmi_debug_set_traversal", "ptmi_debug_rcp_check",
     "ptmi_host_scene_load", "ptmi_host_scene_from_arrays", "ptmi_host_scene_free", "ptmi_host_scene_info",
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
-    "ptmi_host_cdf_record_layout",
+    "ptmi_host_cdf_record_layout", "ptmi_host_image",
+    "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
+    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles",
 ]
 
 
@@ -36,7 +38,8 @@ class Camera(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("spp", C.c_int), ("max_depth", C.c_int), ("sampling_mode", C.c_int), ("seed_base", C.c_uint64),
-                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int), ("mis_bsdf_fraction", C.c_float), ("integrator", C.c_int)]
+                ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int), ("mis_bsdf_fraction", C.c_float), ("integrator", C.c_int),
+                ("download_image", C.c_int)]
 
 
 class Tiling(C.Structure):
@@ -124,6 +127,17 @@ def lib():
         L.ptmi_host_local_row_map.argtypes = [C.c_int, C.POINTER(Tiling), ip, vp]
         L.ptmi_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, vp]
         L.ptmi_host_cdf_record_layout.argtypes = [vp]
+        L.ptmi_host_image.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.ptmi_dist_unique_id.argtypes = [vp]
+        L.ptmi_dist_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.ptmi_dist_finalize.argtypes = [vp]
+        L.ptmi_gather_frame.argtypes = [vp, C.c_int, C.c_int]
+        L.ptmi_gather_wait.argtypes = [vp]
+        L.ptmi_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.ptmi_read_frame.argtypes = [vp, vp, vp]
+        L.ptmi_dist_barrier.argtypes = [vp]
+        L.ptmi_dist_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
+        L.ptmi_debug_place_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -334,7 +348,7 @@ class Renderer:
         self._ck(self.L.ptmi_set_camera(self.h, C.byref(cam)))
 
     def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None, wave_tiles=None, streams=None,
-                   sampling_mode=None, mis_bsdf_fraction=None, integrator=None):
+                   sampling_mode=None, mis_bsdf_fraction=None, integrator=None, download_image=None):
         c = self.config
         if spp is not None: c.spp = int(spp)
         if max_depth is not None: c.max_depth = int(max_depth)
@@ -346,6 +360,7 @@ class Renderer:
         if sampling_mode is not None: c.sampling_mode = int(sampling_mode)
         if mis_bsdf_fraction is not None: c.mis_bsdf_fraction = float(mis_bsdf_fraction)
         if integrator is not None: c.integrator = int(integrator)
+        if download_image is not None: c.download_image = int(bool(download_image))
         self._ck(self.L.ptmi_set_config(self.h, C.byref(c)))
 
     def camera_frame(self):
@@ -379,6 +394,69 @@ class Renderer:
     def copy_image_device(self, d_rgb8_ptr=None, d_radiance_ptr=None):
         """D2D copy of the local rows into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr())."""
         self._ck(self.L.ptmi_copy_image_device(self.h, d_rgb8_ptr, d_radiance_ptr))
+
+    def host_image(self):
+        """RenderState::h_image: the pinned host copy of the local 8-bit rows that render_frame fills when download_image is set
+        (a view, valid until the next update_resolution / close)."""
+        p = C.c_void_p(); n = C.c_uint64()
+        self._ck(self.L.ptmi_host_image(self.h, C.byref(p), C.byref(n)))
+        buf = (C.c_ubyte * n.value).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(-1, self.width, 3)
+
+    # --- multi-GPU frame exchange (RCCL behind the C ABI) ---
+    GATHER_RGB8, GATHER_RADIANCE = 1, 2
+
+    @staticmethod
+    def dist_unique_id():
+        """ncclGetUniqueId: 128 bytes to be shipped from one rank to all ranks (any channel)."""
+        buf = C.create_string_buffer(128)
+        _check(lib().ptmi_dist_unique_id(buf))
+        return buf.raw
+
+    def dist_init(self, unique_id, n_ranks, rank):
+        assert len(unique_id) == 128
+        self._ck(self.L.ptmi_dist_init(self.h, C.c_char_p(unique_id), int(n_ranks), int(rank)))
+
+    def dist_finalize(self):
+        self._ck(self.L.ptmi_dist_finalize(self.h))
+
+    def gather_frame(self, dst_rank=0, what=3):
+        """The one exchange step of a frame; only enqueues (see include/ptmi.h)."""
+        self._ck(self.L.ptmi_gather_frame(self.h, int(dst_rank), int(what)))
+
+    def gather_wait(self):
+        self._ck(self.L.ptmi_gather_wait(self.h))
+
+    def read_frame(self, rgb8=True, radiance=True):
+        rgb = np.zeros((self.height, self.width, 3), np.uint8) if rgb8 else None
+        rad = np.zeros((self.height, self.width, 3), np.float32) if radiance else None
+        self._ck(self.L.ptmi_read_frame(self.h, rgb.ctypes.data if rgb8 else None, rad.ctypes.data if radiance else None))
+        return rgb, rad
+
+    def dist_barrier(self):
+        self._ck(self.L.ptmi_dist_barrier(self.h))
+
+    def dist_allreduce_max(self, value):
+        v = C.c_double(float(value))
+        self._ck(self.L.ptmi_dist_allreduce_max(self.h, C.byref(v)))
+        return v.value
+
+    def debug_place_tiles(self, width, height, n_ranks, row_block, tiles_rgb8=None, tiles_radiance=None):
+        """dst-side row placement of the gather alone: tiles concatenated in rank order -> frame."""
+        n = width * height * 3
+        out_rgb = out_rad = None
+        if tiles_rgb8 is not None:
+            tiles_rgb8 = np.ascontiguousarray(tiles_rgb8, np.uint8).reshape(-1); assert tiles_rgb8.size == n
+            out_rgb = np.zeros((height, width, 3), np.uint8)
+        if tiles_radiance is not None:
+            tiles_radiance = np.ascontiguousarray(tiles_radiance, np.float32).reshape(-1); assert tiles_radiance.size == n
+            out_rad = np.zeros((height, width, 3), np.float32)
+        self._ck(self.L.ptmi_debug_place_tiles(self.h, width, height, n_ranks, row_block,
+                                               tiles_rgb8.ctypes.data if tiles_rgb8 is not None else None,
+                                               tiles_radiance.ctypes.data if tiles_radiance is not None else None,
+                                               out_rgb.ctypes.data if out_rgb is not None else None,
+                                               out_rad.ctypes.data if out_rad is not None else None))
+        return out_rgb, out_rad
 
     # --- test hooks ---
     SWEEP, LANE, STACK, PHASED = 0, 1, 2, 3

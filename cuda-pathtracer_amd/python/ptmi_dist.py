@@ -16,7 +16,21 @@ def row_maps(height, world, row_block):
     return [ptmi.host_local_row_map(height, world, k, row_block).astype(np.int64) for k in range(world)]
 
 
+def dist_init_from_torch(renderer, dist):
+    """ptmi_dist_init for a process that already has a torch.distributed group: rank 0 draws the ncclUniqueId
+    (ptmi_dist_unique_id) and the 128 bytes travel to every rank through the group; the frame exchange itself then runs
+    inside libptmi.so (ptmi_gather_frame), not through torch."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [ptmi.Renderer.dist_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    renderer.dist_init(box[0], world, rank)
+
+
 class FrameGather:
+    """torch.distributed gather of padded tiles + row placement with tensor indexing: the CPU (gloo) rehearsal of the frame
+    exchange used by the tests of the row arithmetic.  On GPUs the exchange is ptmi_gather_frame (csrc/dist.hip)."""
+
     def __init__(self, dist, width, height, world, rank, row_block, device, dst=0, n_send=1):
         self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
         self.width, self.height = width, height

@@ -35,6 +35,7 @@ extern "C" {
 #define PTMI_E_NO_DEVICE  -3   /* no HIP device / wrong architecture */
 #define PTMI_E_HIP        -4   /* a HIP runtime call failed (message carries hipGetErrorString) */
 #define PTMI_E_NOMEM      -5   /* device or host allocation failed (reference: cudaMallocSafe throws, utils/cuda_utils.h:54-60) */
+#define PTMI_E_DIST       -6   /* librccl could not be loaded or an nccl* call failed (message carries ncclGetErrorString) */
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -83,6 +84,9 @@ typedef struct {
     int      integrator;          /* AppConfig::current_integrator (application_state.h:50-53, 283): 0 = PathTracing,
                                    * 1 = Radiosity: renderFrame launches render_radiosity (integrator.h:460-504) - first hit,
                                    * Le + per-primitive radiosity, sqrt gamma - instead of the path tracer */
+    int      download_image;      /* 1: ptmi_render_frame ends like renderFrame() does, with the D2H of the 8-bit image into the
+                                   * ctx's pinned host image (RenderState::h_image, application.h:211) - read it through
+                                   * ptmi_host_image.  0 (default): results stay on the device until asked for */
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).
@@ -150,13 +154,15 @@ int ptmi_scene_get_bvh(const ptmi_ctx*, float* bmin, float* bmax, int* left, int
 /* ---- SceneState::precomputeCDFs (application_state.h:492-585) -----------------------------------------------------
  * Per-primitive 16x16 directional radiosity grids -> the 2120-byte PrecomputedCDF records the guided sampling modes
  * read (render_config.h:24-31).  rgb: n_prims * 256 * 3 floats in load order (n_prims must match the loaded scene);
- * NULL drops the records.  In the reference the grids come out of the radiosity pre-pass (form_factors.h), which is
- * out of scope here: they are an input.  Loading another scene drops the records. */
+ * NULL drops the records.  In the reference the grids come out of the radiosity pre-pass (form_factors.h), here out of
+ * ptmi_run_radiosity_solver (which makes this call itself) or from the caller.  Loading another scene drops the records.
+ * The reference's second path of initGridFromPrimitive (integrator.h:44-54: precomputed_cdfs == nullptr, the grid rebuilt
+ * per hit from the primitive's raw radiosity grid) cannot arise here: records are built whenever grids are set. */
 int ptmi_set_radiosity_grids(ptmi_ctx*, int n_prims, const float* rgb);
 /* host copy of the records, n_prims * 530 dwords (is_valid as an int bit pattern); returns PTMI_E_INVALID if there are none */
 int ptmi_get_precomputed_cdfs(const ptmi_ctx*, float* out);
 /* Per-primitive radiosity (Triangle/Quad::radiosity; n_prims * 3 floats, load order; NULL = zero) shown by the Radiosity
- * integrator.  Like the grids above it is the radiosity solver's output in the reference and an input here. */
+ * integrator: the radiosity solver's output (ptmi_run_radiosity_solver sets it) or the caller's. */
 int ptmi_set_radiosity(ptmi_ctx*, int n_prims, const float* rgb);
 
 /* ---- RadiosityState::runSolver (application_state.h:688-777) + what the UI does right after it (ui_windows.h:185-192):
@@ -213,6 +219,40 @@ int ptmi_read_image(const ptmi_ctx*, unsigned char* rgb8, float* radiance);     
 /* D2D copy of the local rows into caller-owned DEVICE buffers (e.g. the send buffers of an RCCL gather); either may be NULL */
 int ptmi_copy_image_device(const ptmi_ctx*, void* d_rgb8_dst, void* d_radiance_dst);
 
+/* RenderState::h_image (application_state.h:77): the pinned host copy of this rank's 8-bit rows that ptmi_render_frame fills
+ * when config.download_image is set; valid until the next ptmi_update_resolution / ptmi_ctx_destroy. */
+int ptmi_host_image(const ptmi_ctx*, const unsigned char** rgb8, uint64_t* n_bytes);
+
+/* ---- multi-GPU: the frame-end exchange (new in this implementation) ------------------------------------------
+ * One process (or host thread) and one ctx per GPU; every rank loads the same scene and renders its rows
+ * (ptmi_update_resolution with ptmi_tiling {n_ranks, rank, row_block}); no data-path collective.  The ONE exchange step
+ * of a frame is ptmi_gather_frame: every rank's tile goes to dst_rank over RCCL (direct ncclSend per peer /
+ * N-1 ncclRecv on dst in one group: xGMI is point-to-point, every peer pushes over its own link), exact tile sizes, and
+ * a kernel on dst places the rows into the whole frame.  librccl.so.1 is loaded on the first ptmi_dist_* call.
+ *
+ *   rank 0:  ptmi_dist_unique_id(id)  -> ship the 128 bytes to every rank (MPI, a file, torch.distributed, ...)
+ *   all   :  ptmi_dist_init(ctx, id, n_ranks, rank)        (collective: ncclCommInitRank)
+ *   per frame, all ranks: ptmi_render_frame(ctx, ...); ptmi_gather_frame(ctx, 0, PTMI_GATHER_RGB8)
+ *   dst   :  ptmi_read_frame(ctx, rgb8, NULL)  or  ptmi_frame_device(...)
+ *
+ * ptmi_gather_frame only ENQUEUES (a stream of its own): frames are independent, so the next ptmi_render_frame may
+ * start at once; its resolve pass waits on the device for the gather that still reads this rank's tile.
+ * ptmi_gather_wait / ptmi_read_frame / ptmi_dist_barrier wait for it. */
+#define PTMI_UNIQUE_ID_BYTES 128
+#define PTMI_GATHER_RGB8     1     /* the reference's output, 3 B/pixel */
+#define PTMI_GATHER_RADIANCE 2     /* float mean radiance, 12 B/pixel */
+int ptmi_dist_unique_id(void* out_id /* PTMI_UNIQUE_ID_BYTES */);
+int ptmi_dist_init(ptmi_ctx*, const void* id /* PTMI_UNIQUE_ID_BYTES */, int n_ranks, int rank);
+int ptmi_dist_finalize(ptmi_ctx*);                       /* also done by ptmi_ctx_destroy */
+int ptmi_gather_frame(ptmi_ctx*, int dst_rank, int what /* PTMI_GATHER_RGB8 | PTMI_GATHER_RADIANCE */);
+int ptmi_gather_wait(ptmi_ctx*);
+/* dst_rank only: the assembled width x height frame (row 0 = bottom), device pointers (NULL for a part never gathered) */
+int ptmi_frame_device(const ptmi_ctx*, void** d_rgb8, void** d_radiance);
+/* dst_rank only: waits for the gather, then D2H of the whole frame; either may be NULL */
+int ptmi_read_frame(ptmi_ctx*, unsigned char* rgb8, float* radiance);
+int ptmi_dist_barrier(ptmi_ctx*);                        /* all ranks; also drains this rank's gather stream */
+int ptmi_dist_allreduce_max(ptmi_ctx*, double* value);   /* in/out: max over ranks (timing: max-over-ranks of a step time) */
+
 /* ---- host-only halves (no device touched; usable without a GPU) ----------------
  * The parse/convert/subdivide/BVH half of loadScene and the camera/tiling arithmetic, for
  * inspection and for tests of the host logic. */
@@ -237,6 +277,10 @@ int  ptmi_host_cdf_record_layout(int* out10);
 int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows, int* rows_out);
 
 /* ---- unit-test hooks: single stages of the path on the device ------------- */
+/* The destination's row-placement step of ptmi_gather_frame alone: tiles in rank order with their exact sizes
+ * (sum = width*height*3 elements) -> whole frame.  Either pair may be NULL. */
+int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int row_block, const unsigned char* tiles_rgb8,
+                           const float* tiles_radiance, unsigned char* out_rgb8, float* out_radiance);
 /* Overrides how ptmi_bounce walks the BVH (results are identical in every mode): force_mode -1 = automatic,
  * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases;
  * sweep_max_prims = largest scene (primitives)

@@ -26,27 +26,33 @@ def main():
     rows = ptmi_dist.row_maps(H, world, row_block)[rank]
     assert (rows == ptmi.host_local_row_map(H, world, rank, row_block)).all()
     if len(sys.argv) > 5 and sys.argv[5] == "gpu":
-        # the product path: every rank renders ITS tile on the GPU (all ranks share device 0 here), two frames with the
-        # ring of send buffers bench.py uses; rank 0 checks the second gathered frame against the unsharded oracle frame
+        # the product path: every rank renders ITS tile on the GPU (all ranks share device 0 here, so RCCL itself cannot
+        # carry them: it refuses two ranks on one device), two frames; the tiles travel by gloo in the exact sizes and order
+        # ptmi_gather_frame receives them, rank 0 places them with the product's kernel and checks the second frame
+        # against the unsharded oracle frame
         r = ptmi.Renderer(0)
         r.load_scene(os.path.join(SCENES, "cbox.obj"))
         r.update_resolution(W, H, n_ranks=world, rank=rank, row_block=row_block)
         r.set_config(spp=spp, max_depth=5)
-        fg2 = ptmi_dist.FrameGather(dist, W, H, world, rank, row_block, torch.device("cpu"), n_send=2)
         state = np.zeros((H * W, 6), np.uint32)
         out = None
         for frame in range(2):
             r.render_frame()
             rgb, rad = r.read_image()
-            fg2.sends_rgb[frame & 1][: len(rows)] = torch.from_numpy(rgb); fg2.sends_rad[frame & 1][: len(rows)] = torch.from_numpy(rad)
-            out = fg2.gather(frame & 1)
+            # exact tile sizes, rank order: what ptmi_gather_frame's ncclRecv calls deliver into the staging buffers
+            tiles = [None] * world if rank == 0 else None
+            dist.gather_object((rgb, rad), tiles, dst=0)
+            if rank == 0:
+                # the product's own placement kernel (csrc/dist.hip: ptmi_place_tiles) assembles the frame
+                out = r.debug_place_tiles(W, H, world, row_block, np.concatenate([t[0].reshape(-1) for t in tiles]),
+                                          np.concatenate([t[1].reshape(-1) for t in tiles]))
         r.close()
         ok = True
         if rank == 0:
-            frad, frgb = out
+            frgb, frad = out
             for frame in range(2):
                 orgb, orad, _ = o.render(default_camera(), W, H, spp, n_threads=2, rng_state=state, reset_rng=(frame == 0))
-            ok = bool((frad.numpy().view(np.uint32) == orad.view(np.uint32)).all() and (frgb.numpy() == orgb).all())
+            ok = bool((frad.view(np.uint32) == orad.view(np.uint32)).all() and (frgb == orgb).all())
             print("dist-gather-gpu", "OK" if ok else "MISMATCH", W, H, world, row_block, flush=True)
         flag = torch.tensor([1 if ok else 0])
         dist.broadcast(flag, src=0)

@@ -344,6 +344,32 @@ def test_errors_are_reported_not_swallowed(R):
     with pytest.raises(ptmi.PtmiError):
         R.set_config(spp=0)
     R.set_config(spp=1)
+    # a rejected config changes nothing: spp 7 must not be applied when `streams` is out of range
+    R.update_resolution(32, 32); R.set_config(spp=2, max_depth=5)
+    R.render_frame(); want = R.read_image()[1].copy()
+    R.config.streams = 99
+    with pytest.raises(ptmi.PtmiError):
+        R.set_config(spp=7)
+    R.config.streams = 0; R.config.spp = 2
+    R.update_resolution(32, 32)
+    st = R.render_frame()
+    assert st.samples == 32 * 32 * 2 and (bits(R.read_image()[1]) == bits(want)).all()
+    R.set_config(spp=1)
+
+
+def test_render_frame_downloads_the_image_like_the_reference(R):
+    """config.download_image: ptmi_render_frame ends with the D2H of the 8-bit image into the ctx's pinned host image
+    (RenderState::h_image, application.h:211)"""
+    R.load_scene(os.path.join(SCENES, "cbox.obj"))
+    R.update_resolution(80, 60); R.set_config(spp=4, max_depth=5, download_image=True)
+    R.render_frame()
+    host = R.host_image().copy()
+    rgb, _ = R.read_image()
+    assert host.shape == rgb.shape and (host == rgb).all() and int(host.max()) > 0
+    R.set_config(integrator=1)                     # the Radiosity integrator's frame is downloaded too
+    R.render_frame()
+    assert (R.host_image() == R.read_image()[0]).all()
+    R.set_config(integrator=0, download_image=False)
 
 
 # ------------------------------------------------------------------------------------------------
