@@ -537,12 +537,24 @@ int ptmi_debug_place_tiles(ptmi_ctx* c, int width, int height, int n_ranks, int 
 int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, int* out_mode) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
-        need(force_mode >= -1 && force_mode <= 3, "force_mode must be -1..3");
+        need(force_mode >= -1 && force_mode <= 4, "force_mode must be -1..4");
         need(sweep_max_prims >= 0, "sweep_max_prims must be >= 0");
         SceneState& s = c->app.scene;
         s.force_traversal = force_mode; s.sweep_max_prims = sweep_max_prims;
         s.chooseTraversal();
         if (out_mode) *out_mode = s.d_nodes ? s.d_scene.traversal : -1;
+    });
+}
+
+int ptmi_debug_set_packed_min_nodes(ptmi_ctx* c, int min_nodes, int* n_positions) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(min_nodes >= 0, "min_nodes must be >= 0");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        SceneState& s = c->app.scene;
+        s.packed_min_nodes = min_nodes;
+        if (s.d_nodes) { s.buildPacked(); s.chooseTraversal(); }
+        if (n_positions) *n_positions = s.d_scene.n_pos;
     });
 }
 

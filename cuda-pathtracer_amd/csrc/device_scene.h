@@ -50,7 +50,26 @@ struct DeviceScene {
     // Per-primitive radiosity (Triangle/Quad::radiosity, the radiosity solver's output in the reference): float4 per
     // LEAF-ORDER slot, read by ptmi_render_radiosity only.  nullptr = all zero (as after loading a scene).
     const float4* radiosity = nullptr;
+    // TRAVERSAL_PACKED (scenes too large for LDS): the same tree in a cache-line-friendly order, see PACKED LAYOUT below.
+    const float4* gnodes = nullptr;    // 2 float4 per record position
+    int n_pos = 0;                     // record positions (incl. padding); a cursor >= n_pos ends the walk
+    const float* gprims = nullptr;     // triangle-only scenes: 9 floats (v0, e1, e2) per leaf-order slot; nullptr: use prims
+    const float4* gmats = nullptr;     // (normal.xyz, bits(row of mtab)) per leaf-order slot
+    const float4* mtab = nullptr;      // distinct (Kd, Ke) pairs, 2 float4 per row
+    const int* load_index = nullptr;   // leaf-order slot -> load-order primitive index (guided sampling reads cdfs through it)
 };
+// PACKED LAYOUT.  On the 1 M-triangle scene the phased walk is bound by the rate at which L2 misses are served (it runs at
+// the same speed with 2 and with 7 waves per SIMD, with and without half of its node reads moved to LDS): what counts is the
+// number of distinct 128-byte lines a ray touches.  In pre-order a node's left child shares its line, its right child never
+// does.  Here the two children of a node are ONE 64-byte pair, and pairs are laid out in pre-order of their parents, so a
+// 128-byte line holds (L, R, LL, LR): the sibling that the walk comes back to after a subtree - or goes to at once when the
+// left box is missed - arrived with the first fetch.  Measured on 1000 rays of that scene: 43 -> 28 distinct node lines per
+// ray.  Links are explicit record positions (the tree and the visiting order are the reference's, scene.h:63-106):
+//   inner  (min, bits(skip position)) (max, bits(left child position))      right child = left + 1; positions > 0
+//   leaf   (min, bits(first slot << 3 | count)) (max, bits(~next position)) count <= 7; next = pre-order successor
+//   position n_pos = "past the end".  Record 1 pads the root to a pair.
+// Primitives of triangle-only scenes shrink from 48 to 36 bytes (three 12-byte loads) and the material record from 48 to 16
+// bytes + a table of the distinct (Kd, Ke) pairs: fewer lines per leaf and per hit, and a smaller footprint in L2/MALL.
 constexpr int kCdfDwords = 530, kCdfPdf = 0, kCdfRowSums = 256, kCdfMarginal = 264, kCdfRowCdfs = 272, kCdfTotal = 528, kCdfValid = 529;
 
 // How ptmi_bounce walks the BVH.  All three visit the same nodes and primitives in the same order per ray.
@@ -61,6 +80,7 @@ enum TraversalMode {
     TRAVERSAL_STACK = 2,   // trees deeper than 62: explicit LDS stack with the reference's drop rule (scene.h:101-105)
     TRAVERSAL_PHASED = 3,  // large scenes: the stackless per-lane walk with wave-scheduled phases (ptmi_bounce_phased):
                            // lanes whose ray ends early shade and start their next segment instead of idling
+    TRAVERSAL_PACKED = 4,  // scenes too large for LDS: PHASED over the packed layout (sibling pairs, 36-byte triangles)
 };
 
 struct PathState {

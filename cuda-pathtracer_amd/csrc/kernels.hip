@@ -160,6 +160,17 @@ __device__ __forceinline__ void leaf_prim(const float4* __restrict__ prims, int 
     slot_hit = closer ? k : slot_hit;
 }
 
+// The same for the 36-byte triangle records of the packed layout (v0, e1, e2: three 12-byte loads)
+struct f3p { float x, y, z; };
+__device__ __forceinline__ void leaf_prim_packed(const float* __restrict__ gprims, int k, f3 o, f3 d, float t_lo, float& closest_t, int& slot_hit) {
+    const f3p* r = reinterpret_cast<const f3p*>(gprims) + 3 * (size_t)k;
+    const f3p v0 = r[0], e1 = r[1], e2 = r[2];
+    float tt = 0.0f;
+    const bool acc = mt_accept(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), o, d, 1e-8f, t_lo, closest_t, tt);
+    closest_t = acc ? tt : closest_t;
+    slot_hit = acc ? k : slot_hit;
+}
+
 // ---- TRAVERSAL_STACK: Scene::intersect_bvh_optimized (scene.h:50-110) with its explicit stack ------------------
 // `stack` points at this lane's column of the LDS stack (entry e lives at stack[e * kBlock]).  The node about to be
 // visited is kept in a register instead of being pushed and popped again; the reference's "drop both children when
@@ -469,13 +480,28 @@ __device__ __forceinline__ f3 sample_mis(const float* __restrict__ g, f3 normal,
 // Returns true while the pixel still has a ray to trace; false once all spp samples are done.
 // GUIDED: the grid / MIS branches of integrator.h:232-263 are compiled in (sampling_mode != SAMPLING_BSDF with CDF
 // records present); the plain BSDF instantiation carries none of that code.
-template <bool STATS, bool GUIDED>
-__device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const float4* mats, const float* cdfs, PathRegs& p,
+// Material record of leaf-order slot k: plain layout mats[3k..3k+2], packed layout (normal, table row) + (Kd, Ke) table.
+struct MatSource { const float4* mats; const float4* mtab; const int* load_index; };
+template <bool PACKED>
+__device__ __forceinline__ void fetch_material(const MatSource& ms, int k, f3& n, f3& bsdf, f3& Le, int& row) {
+    if (PACKED) {
+        const float4 m = ms.mats[k];
+        n = xyz(m); row = __float_as_int(m.w);
+        bsdf = xyz(ms.mtab[2 * row]); Le = xyz(ms.mtab[2 * row + 1]);
+    } else {
+        const float4 m = ms.mats[3 * k];
+        n = xyz(m); row = __float_as_int(m.w);                                    // here: the load-order primitive index
+        bsdf = xyz(ms.mats[3 * k + 1]); Le = xyz(ms.mats[3 * k + 2]);
+    }
+}
+template <bool STATS, bool GUIDED, bool PACKED = false>
+__device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const MatSource& ms, const float* cdfs, PathRegs& p,
                                            bool hit, float t, int k, LaneCounters& cn) {
     bool end_sample = !hit;                                                       // integrator.h:198-201
     if (hit) {
         if (STATS) cn.hits++;
-        const f3 n = xyz(mats[3 * k]), bsdf = xyz(mats[3 * k + 1]), Le = xyz(mats[3 * k + 2]);
+        f3 n, bsdf, Le; int row;
+        fetch_material<PACKED>(ms, k, n, bsdf, Le, row);
         const f3 hp = p.o + t * p.d;                                              // triangle.h:90
         p.L = p.L + p.tp * Le;                                                    // integrator.h:204
         if (p.depth > 2) {                                                        // integrator.h:207-212
@@ -492,7 +518,7 @@ __device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap&
                 // initGridFromPrimitive (integrator.h:31-57): the primitive's precomputed record, if it is valid
                 const float* g = nullptr;
                 if (GUIDED) {
-                    const float* rec = cdfs + (size_t)__float_as_int(mats[3 * k].w) * kCdfDwords;
+                    const float* rec = cdfs + (size_t)(PACKED ? ms.load_index[k] : row) * kCdfDwords;
                     if (__float_as_int(rec[kCdfValid]) != 0) g = rec;
                 }
                 if (GUIDED && g) {
@@ -609,7 +635,7 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_s
         if (STATS && alive) cn.rays++;
         const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
                                                                p.o, p.d, 1e-4f, FLT_MAX, t, k, cn);
-        if (alive) alive = shade_step<STATS, GUIDED>(a.fp, a.tm, mats, a.sc.cdfs, p, hit, t, k, cn);
+        if (alive) alive = shade_step<STATS, GUIDED>(a.fp, a.tm, MatSource{mats, nullptr, nullptr}, a.sc.cdfs, p, hit, t, k, cn);
     }
 
     if (active) store_path(a.st, slot, p);
@@ -626,13 +652,16 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_s
 #ifndef PTMI_NODE_BURST
 #define PTMI_NODE_BURST 3
 #endif
-template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED>
+template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
     extern __shared__ float4 smem[];
+    static_assert(!(PACKED && LDS_GEOM), "the packed layout is for scenes that do not fit LDS");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
     const float4 *nodes, *prims, *mats;
     stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
+    if (PACKED) nodes = a.sc.gnodes;
+    const MatSource ms = PACKED ? MatSource{a.sc.gmats, a.sc.mtab, a.sc.load_index} : MatSource{mats, nullptr, nullptr};
     if (GUIDED) fill_grid_solid_angles();
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     LaneCounters cn = {0, 0, 0, 0};
 
     enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
-    const int n_nodes = a.sc.n_nodes, prim_stride = a.sc.prim_stride;
+    const int n_nodes = PACKED ? a.sc.n_pos : a.sc.n_nodes, prim_stride = a.sc.prim_stride;     // cursor >= n_nodes: walk finished
     const float t_min = 1e-4f, t_lo = mt_t_lo(t_min);
     int phase = alive ? PH_NODE : PH_DONE;
     int segs_left = a.segments;
@@ -668,10 +697,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
                     if (STATS) cn.node_visits++;
                     const int na = __float_as_int(n0.w), nb = __float_as_int(n1.w);
                     const bool pass = box_hit(n0, n1, p.o, inv, t_min, closest_t);
-                    int next = cur + 1;
-                    if (nb < 0) {
-                        if (pass) { pk = na; pend = na - nb; phase = PH_PRIM; }
-                    } else if (!pass) next = na;
+                    int next;
+                    if (PACKED) {                                      // explicit links (device_scene.h, PACKED LAYOUT)
+                        if (nb < 0) {
+                            next = ~nb;
+                            if (pass) { pk = na >> 3; pend = pk + (na & 7); phase = PH_PRIM; }
+                        } else next = pass ? nb : na;
+                    } else {                                           // pre-order: left child = cur + 1, a = skip index
+                        next = cur + 1;
+                        if (nb < 0) {
+                            if (pass) { pk = na; pend = na - nb; phase = PH_PRIM; }
+                        } else if (!pass) next = na;
+                    }
                     cur = next;
                     if (phase == PH_NODE && cur >= n_nodes) phase = PH_SHADE;
                 }
@@ -679,13 +716,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
         } else if (c_prim >= c_shade) {
             if (phase == PH_PRIM) {                                    // one primitive of the leaf loop (scene.h:85-99)
                 if (STATS) cn.prim_tests++;
-                leaf_prim<HAS_QUADS>(prims, prim_stride, pk, p.o, p.d, t_lo, closest_t, slot_hit);
+                if (PACKED && !HAS_QUADS) leaf_prim_packed(a.sc.gprims, pk, p.o, p.d, t_lo, closest_t, slot_hit);
+                else leaf_prim<HAS_QUADS>(prims, prim_stride, pk, p.o, p.d, t_lo, closest_t, slot_hit);
                 pk++;
                 if (pk == pend) phase = cur >= n_nodes ? PH_SHADE : PH_NODE;
             }
         } else {
             if (phase == PH_SHADE) {
-                const bool more = shade_step<STATS, GUIDED>(a.fp, a.tm, mats, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn);
+                const bool more = shade_step<STATS, GUIDED, PACKED>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn);
                 segs_left--;
                 if (!more) { alive = false; phase = PH_DONE; }
                 else if (segs_left == 0) phase = PH_DONE;              // state goes back to HBM with the next ray ready
@@ -739,6 +777,21 @@ static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStr
     if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true>), grid, dim3(kBlock), lds, s, a);
     else hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false>), grid, dim3(kBlock), lds, s, a);
 }
+template <bool Q_, bool S_>
+static void launch_packed_one(const BounceArgs& a, dim3 grid, hipStream_t s) {
+    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true>), grid, dim3(kBlock), 0, s, a);
+}
+static void launch_packed(const BounceArgs& a, dim3 grid, hipStream_t s) {
+
+    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
+    switch (key) {
+        case 0: launch_packed_one<false, false>(a, grid, s); break;
+        case 1: launch_packed_one<false, true>(a, grid, s); break;
+        case 2: launch_packed_one<true, false>(a, grid, s); break;
+        default: launch_packed_one<true, true>(a, grid, s); break;
+    }
+}
 template <bool G_>
 static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
@@ -760,6 +813,7 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
     if (sc.traversal == TRAVERSAL_SWEEP) launch_bounce_mode<TRAVERSAL_SWEEP>(a, grid, lds, s);
     else if (sc.traversal == TRAVERSAL_LANE) launch_bounce_mode<TRAVERSAL_LANE>(a, grid, lds, s);
     else if (sc.traversal == TRAVERSAL_PHASED) { if (sc.lds_resident) launch_phased<true>(a, grid, lds, s); else launch_phased<false>(a, grid, lds, s); }
+    else if (sc.traversal == TRAVERSAL_PACKED) launch_packed(a, grid, s);
     else launch_bounce_mode<TRAVERSAL_STACK>(a, grid, lds, s);
 }
 
@@ -897,7 +951,7 @@ void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const 
     const size_t lds = (size_t)sc.stack_entries * kBlock * sizeof(int);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
 #define PTMI_DBG(M_, Q_) hipLaunchKernelGGL((ptmi_debug_intersect_k<M_, Q_>), grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm)
-    const int walk = sc.traversal == TRAVERSAL_PHASED ? TRAVERSAL_LANE : sc.traversal;   // the phased kernel walks like LANE
+    const int walk = sc.traversal == TRAVERSAL_PHASED || sc.traversal == TRAVERSAL_PACKED ? TRAVERSAL_LANE : sc.traversal;   // the phased kernels walk like LANE
     switch (walk * 2 + (sc.has_quads ? 1 : 0)) {
         case 0: PTMI_DBG(TRAVERSAL_SWEEP, false); break;
         case 1: PTMI_DBG(TRAVERSAL_SWEEP, true); break;

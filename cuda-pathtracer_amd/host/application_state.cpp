@@ -1,9 +1,12 @@
 #include "application_state.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
+#include <limits>
 #include <cctype>
 #include <cstring>
+#include <map>
 
 namespace ptmi {
 
@@ -85,6 +88,7 @@ void SceneState::cleanup() {
     if (d_mats) (void)hipFree(d_mats);
     if (d_precomputed_cdfs) (void)hipFree(d_precomputed_cdfs);
     if (d_radiosity) (void)hipFree(d_radiosity);
+    freePacked();
     d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr; d_radiosity = nullptr;
     h_precomputed_cdfs.clear(); h_radiosity_grids.clear(); h_count_grids.clear(); h_filtered_formfactor.clear(); h_filtered_radiosity.clear();
     d_scene = DeviceScene();
@@ -191,7 +195,86 @@ void SceneState::upload() {
     // LDS residency: the whole scene is staged per workgroup while it leaves room for >= 2 workgroups per CU
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
+    buildPacked();
     chooseTraversal();
+}
+
+void SceneState::freePacked() {
+    void* ptrs[] = {d_gnodes, d_gmats, d_mtab, d_gprims, d_load_index};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_gnodes = d_gmats = d_mtab = nullptr; d_gprims = nullptr; d_load_index = nullptr;
+    d_scene.gnodes = nullptr; d_scene.n_pos = 0; d_scene.gprims = nullptr; d_scene.gmats = nullptr; d_scene.mtab = nullptr;
+    d_scene.load_index = nullptr;
+}
+
+// The packed layout of csrc/device_scene.h: same tree, same visiting order, records placed so that a ray touches fewer lines.
+void SceneState::buildPacked() {
+    freePacked();
+    const int n = (int)bvh_nodes.size(), n_prims = (int)h_primitives.size();
+    if (!d_nodes || d_scene.lds_resident || bvh_depth > 62 || n < packed_min_nodes || n_prims >= (1 << 28)) return;
+    for (const BVHNode& b : bvh_nodes) if (b.isLeaf() && b.prim_count > 7) return;      // the leaf record packs count into 3 bits
+    auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
+    std::vector<int> pos((size_t)n, -1), subtree((size_t)n, 1), stack;
+    for (int i = n; i-- > 0;)
+        if (!bvh_nodes[i].isLeaf()) subtree[i] = 1 + subtree[bvh_nodes[i].left_child] + subtree[bvh_nodes[i].right_child];
+    int n_pos = 2;                                     // root at 0, position 1 pads it to a pair
+    pos[0] = 0;
+    stack.push_back(0);
+    while (!stack.empty()) {                           // pairs in pre-order of their parents
+        const int x = stack.back(); stack.pop_back();
+        if (bvh_nodes[x].isLeaf()) continue;
+        const int l = bvh_nodes[x].left_child, r = bvh_nodes[x].right_child;
+        pos[l] = n_pos; pos[r] = n_pos + 1; n_pos += 2;
+        stack.push_back(r); stack.push_back(l);
+    }
+    auto position_of = [&](int pre) { return pre >= n ? n_pos : pos[pre]; };
+    const float inf = std::numeric_limits<float>::infinity();
+    std::vector<float4> g((size_t)2 * n_pos, make_float4(inf, inf, inf, 0.0f));
+    g[2] = make_float4(inf, inf, inf, bits(0)); g[3] = make_float4(-inf, -inf, -inf, bits(~n_pos));   // padding: an empty leaf nobody links to
+    for (int i = 0; i < n; i++) {
+        const BVHNode& b = bvh_nodes[i];
+        int a_, b_;
+        if (b.isLeaf()) { a_ = (b.left_child << 3) | b.prim_count; b_ = ~position_of(i + 1); }
+        else { a_ = position_of(i + subtree[i]); b_ = pos[b.left_child]; }
+        g[2 * (size_t)pos[i]] = make_float4(b.bbox.min.x, b.bbox.min.y, b.bbox.min.z, bits(a_));
+        g[2 * (size_t)pos[i] + 1] = make_float4(b.bbox.max.x, b.bbox.max.y, b.bbox.max.z, bits(b_));
+    }
+    // materials: (normal, table row) per slot + the distinct (Kd, Ke) pairs; load-order index on its own
+    std::map<std::array<uint32_t, 6>, int> rows;
+    std::vector<float4> gm((size_t)n_prims), tab;
+    std::vector<int> load_index((size_t)n_prims);
+    std::vector<float> gp;
+    if (!num_quads) gp.resize((size_t)9 * n_prims);
+    for (int k = 0; k < n_prims; k++) {
+        const Primitive& p = h_primitives[bvh_indices[k]];
+        std::array<uint32_t, 6> key;
+        const float kv[6] = {p.bsdf.x, p.bsdf.y, p.bsdf.z, p.Le.x, p.Le.y, p.Le.z};
+        std::memcpy(key.data(), kv, sizeof kv);
+        auto it = rows.find(key);
+        if (it == rows.end()) {
+            it = rows.emplace(key, (int)rows.size()).first;
+            tab.push_back(make_float4(p.bsdf.x, p.bsdf.y, p.bsdf.z, 0.0f)); tab.push_back(make_float4(p.Le.x, p.Le.y, p.Le.z, 0.0f));
+        }
+        gm[k] = make_float4(p.normal.x, p.normal.y, p.normal.z, bits(it->second));
+        load_index[k] = bvh_indices[k];
+        if (!num_quads) {
+            const f3 e1 = p.v[1] - p.v[0], e2 = p.v[2] - p.v[0];         // the float subtraction the reference does per test
+            const float rec[9] = {p.v[0].x, p.v[0].y, p.v[0].z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z};
+            std::memcpy(&gp[(size_t)9 * k], rec, sizeof rec);
+        }
+    }
+    auto upload_vec = [&](const void* src, size_t bytes, const char* name) {
+        void* d = hipMallocSafe(bytes, name);
+        PTMI_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        return d;
+    };
+    d_gnodes = (float4*)upload_vec(g.data(), g.size() * sizeof(float4), "d_gnodes");
+    d_gmats = (float4*)upload_vec(gm.data(), gm.size() * sizeof(float4), "d_gmats");
+    d_mtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_mtab");
+    d_load_index = (int*)upload_vec(load_index.data(), load_index.size() * sizeof(int), "d_load_index");
+    if (!num_quads) d_gprims = (float*)upload_vec(gp.data(), gp.size() * sizeof(float), "d_gprims");
+    d_scene.gnodes = d_gnodes; d_scene.n_pos = n_pos; d_scene.gprims = d_gprims; d_scene.gmats = d_gmats; d_scene.mtab = d_mtab;
+    d_scene.load_index = d_load_index;
 }
 
 void SceneState::setRadiosity(const float* rgb) {
@@ -404,10 +487,12 @@ void SceneState::chooseTraversal() {
     if (!d_nodes) return;
     if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
-    else d_scene.traversal = TRAVERSAL_PHASED;   // measured faster than the segment-synchronous LANE walk from 128 primitives up
-                                                 // (LDS-resident or not); LANE stays available through the override
+    else d_scene.traversal = d_scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED;
+    // PHASED: measured faster than the segment-synchronous LANE walk from 128 primitives up (LDS-resident or not); PACKED: the
+    // phased walk over the packed layout of scenes too large for LDS; LANE stays available through the override
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
     if (d_scene.traversal == TRAVERSAL_SWEEP && !d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;   // the sweep reads through LDS
+    if (d_scene.traversal == TRAVERSAL_PACKED && !d_scene.gnodes) d_scene.traversal = TRAVERSAL_PHASED;
 }
 
 // ------------------------------------------------------------------------------------------------

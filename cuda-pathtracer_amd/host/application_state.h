@@ -59,6 +59,11 @@ struct SceneState {
     std::string scene_file;
 
     float4 *d_nodes = nullptr, *d_prims = nullptr, *d_mats = nullptr;
+    // packed layout for TRAVERSAL_PACKED (csrc/device_scene.h), built for scenes of at least packed_min_nodes nodes
+    float4 *d_gnodes = nullptr, *d_gmats = nullptr, *d_mtab = nullptr;
+    float* d_gprims = nullptr;
+    int* d_load_index = nullptr;
+    int packed_min_nodes = 8192;
     DeviceScene d_scene;
     // guided sampling: per-primitive PrecomputedCDF records (render_config.h:24-31), load order
     std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords: host copy, fetched on demand (precomputedCdfsHost)
@@ -90,12 +95,14 @@ struct SceneState {
     void loadSceneHost(const std::string& filename, int subdivision_count, bool convert_quads);
     void loadSceneArraysHost(std::vector<Primitive> prims);
     void chooseTraversal();                          // picks d_scene.traversal from size/depth and the two knobs below
+    void buildPacked();                              // (re)builds the packed layout if the scene qualifies; chooseTraversal() after it
     void cleanup();                                  // application_state.h:466-490
     ~SceneState() { cleanup(); }
 
 private:
     void buildBVH();                                 // RayTracingManager::buildAccelStructure (ray_tracing_backend.h:81-129)
     void upload();                                   // SoA re-layout + H2D
+    void freePacked();
 };
 
 // RadiosityState — application_state.h:200-216, 688-787: the radiosity pre-pass that produces what the guided sampling

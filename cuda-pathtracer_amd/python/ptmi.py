@@ -27,7 +27,7 @@ EXPORTS = [
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
-    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles",
+    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes",
 ]
 
 
@@ -137,6 +137,7 @@ def lib():
         L.ptmi_read_frame.argtypes = [vp, vp, vp]
         L.ptmi_dist_barrier.argtypes = [vp]
         L.ptmi_dist_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
+        L.ptmi_debug_set_packed_min_nodes.argtypes = [vp, C.c_int, ip]
         L.ptmi_debug_place_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -459,13 +460,19 @@ class Renderer:
         return out_rgb, out_rad
 
     # --- test hooks ---
-    SWEEP, LANE, STACK, PHASED = 0, 1, 2, 3
+    SWEEP, LANE, STACK, PHASED, PACKED = 0, 1, 2, 3, 4
 
     def set_traversal(self, force_mode=-1, sweep_max_prims=64):
         """Returns the traversal mode in effect for the loaded scene (-1 if none)."""
         m = C.c_int(-1)
         self._ck(self.L.ptmi_debug_set_traversal(self.h, int(force_mode), int(sweep_max_prims), C.byref(m)))
         return m.value
+
+    def set_packed_min_nodes(self, min_nodes=8192):
+        """Smallest tree (BVH nodes) that gets the packed layout of traversal mode PACKED; returns the record positions built."""
+        n = C.c_int()
+        self._ck(self.L.ptmi_debug_set_packed_min_nodes(self.h, int(min_nodes), C.byref(n)))
+        return n.value
 
     def debug_rcp_check(self, first_bits, count):
         bad = C.c_uint64(); first = C.c_uint32()

@@ -282,11 +282,16 @@ int  ptmi_host_local_row_map(int height, const ptmi_tiling* tiling, int* n_rows,
 int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int row_block, const unsigned char* tiles_rgb8,
                            const float* tiles_radiance, unsigned char* out_rgb8, float* out_radiance);
 /* Overrides how ptmi_bounce walks the BVH (results are identical in every mode): force_mode -1 = automatic,
- * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases;
+ * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases,
+ * 4 = 3 over the packed layout (sibling-pair node order, 36-byte triangles; only where that layout was built, else 3);
  * sweep_max_prims = largest scene (primitives)
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
 int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int* out_mode);
+/* The packed layout of traversal mode 4 is built for scenes that do not fit LDS, have at least min_nodes BVH nodes (default
+ * 8192), a tree no deeper than 62 and no leaf of more than 7 primitives.  Applies to the loaded scene at once and to later
+ * loads; n_positions (may be NULL) receives the number of record positions built (0 = none).  Results do not depend on it. */
+int ptmi_debug_set_packed_min_nodes(ptmi_ctx*, int min_nodes, int* n_positions);
 /* Scene::intersect (scene.h:39-110) for n rays given as-is (no normalisation). out_*: n each; p/nrm 3n. */
 int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm);

@@ -13,6 +13,8 @@ import ptmi
 from oracle_binding import (OracleScene, SCENES, Camera as OCamera, camera_frame, camera_ray, default_camera,
                             oracle_lib, rng_stream)
 
+from guided_fixtures import synthetic_radiosity_grids
+
 pytestmark = pytest.mark.gpu
 F = np.float32
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -182,6 +184,41 @@ def test_every_traversal_mode_gives_the_same_frame(R, mode, name, sub, conv):
             assert g["hit"][i] == h.hit and g["prim"][i] == h.prim and (not h.hit or bits(g["t"][i]) == bits(F(h.t)))
     finally:
         R.set_traversal(-1)
+
+
+@pytest.mark.parametrize("name,sub,conv,sampling", [("cbox.obj", 3, False, 0), ("cbox_quads.obj", 4, False, 0), ("cbox_quads.obj", 3, True, 3),
+                                                    ("cbox.obj", 5, False, 0), ("cbox.obj", 4, False, 1)])
+def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
+    """PACKED: the phased walk over sibling-pair node records with explicit links, 36-byte triangle records and the material
+    table.  Frame and workload counters must equal the oracle's and the pre-order PHASED walk's - triangles and native quads,
+    guided sampling (records reached through load_index), counters on/off, several segments-per-launch."""
+    path = os.path.join(SCENES, name)
+    R.load_scene(path, sub, conv)
+    o = OracleScene.load(path, sub, conv)
+    try:
+        assert R.set_packed_min_nodes(16) > R.scene_info()["n_bvh_nodes"]          # pairs: root + padding + 2 per inner node
+        assert R.set_traversal(-1) == R.PACKED
+        if sampling:
+            grids = synthetic_radiosity_grids(o.n_prims, seed=sampling)
+            R.set_radiosity_grids(grids); o.set_radiosity_grids(grids); o.set_mis_fraction(0.5)
+        W, H, spp = 96, 50, 5
+        orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=6, sampling_mode=sampling)
+        for stats in (True, False):
+            for seg in (0, 1, 5):
+                R.update_resolution(W, H)
+                R.set_config(spp=spp, max_depth=6, collect_stats=stats, segments_per_launch=seg, sampling_mode=sampling, mis_bsdf_fraction=0.5)
+                st = R.render_frame()
+                rgb, rad = R.read_image()
+                assert_same_image(rgb, rad, orgb, orad, f"{name} packed stats {stats} seg {seg}")
+                if stats:
+                    assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        assert R.set_traversal(R.PHASED) == R.PHASED
+        R.update_resolution(W, H); R.render_frame()
+        assert_same_image(*R.read_image(), orgb, orad, "phased")
+        assert R.set_packed_min_nodes(1 << 30) == 0 and R.set_traversal(-1) == R.PHASED      # no packed layout: the pre-order walk
+        assert R.set_traversal(R.PACKED) == R.PHASED
+    finally:
+        R.set_traversal(-1); R.set_packed_min_nodes(8192); R.set_config(sampling_mode=0, segments_per_launch=0, collect_stats=False)
 
 
 def test_deep_tree_uses_the_stack_walk_and_the_references_drop_rule(R):
@@ -375,8 +412,6 @@ def test_render_frame_downloads_the_image_like_the_reference(R):
 # ------------------------------------------------------------------------------------------------
 # guided sampling modes: grid / MIS over per-primitive PrecomputedCDF records
 # ------------------------------------------------------------------------------------------------
-from guided_fixtures import synthetic_radiosity_grids  # noqa: E402
-
 
 @pytest.mark.parametrize("name,sub,conv,trav", [("cbox.obj", 0, False, -1), ("cbox_quads.obj", 0, False, -1),
                                                 ("cbox.obj", 1, False, -1), ("cbox.obj", 0, False, 1), ("cbox.obj", 2, False, 2)])
