@@ -202,20 +202,20 @@ def roofline_block(name, cfg, m, exact_workload):
     return out
 
 
-def measure(r, cfg, steps, warmup, step_fn, barrier, segments, reduce_max):
-    """counters frame (untimed, stats build) + warmup + `steps` timed frames of the loaded workload"""
+def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pipelined=True):
+    """counters frame (untimed, stats build) + warmup + `steps` timed frames of the loaded workload.
+    run_steps(k, stats, pipelined) renders k steps (frames) and returns the list of their ptmi_stats."""
     r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False)
     st_counts = r.render_frame()
     quads = r.scene_info()["n_quads"] > 0
     bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
     r.set_config(collect_stats=False)
-    for _ in range(warmup):
-        step_fn(False)
+    if warmup:
+        run_steps(warmup, False, pipelined)
     kernel_ms = 0.0; launches = 0; visits = 0; frame_dev_s = 0.0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        st = step_fn(True)
+    for st in run_steps(steps, True, pipelined):
         kernel_ms += st.bounce_kernel_ms; launches += st.bounce_launches; visits += st.path_visits; frame_dev_s += st.seconds
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0)
@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather", choices=("rgb8", "radiance", "both"), default="rgb8", help="what the frame-end gather moves (N > 1)")
+    ap.add_argument("--pipeline", action="store_true", help="render the K steps as ONE pipelined batch (ptmi_render_frames) instead of one "
+                    "ptmi_render_frame call per step; without it the batch rate is still reported as value_pipelined_batch (N = 1)")
     # profile pass (tools/profile.sh): exactly `steps` frames of the timing build of the kernel, nothing else on the GPU
     ap.add_argument("--profile-pass", action="store_true", help=argparse.SUPPRESS)
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: ranks share devices and the gather
@@ -303,20 +305,34 @@ def main():
     elif use_dist:
         fg = ptmi_dist.FrameGather(dist, cfg["width"], cfg["height"], world, rank, row_block, torch.device("cpu"))
 
-    def step(stats):
-        # Frames are independent, so the exchange of frame k overlaps the rendering of frame k + 1: ptmi_gather_frame only
-        # ENQUEUES the RCCL sends/receives and the row placement (library-owned stream); the next render_frame runs
-        # meanwhile and its resolve pass waits on the device for the gather that still reads the tile.
-        # Everything outstanding is drained by barrier() before the clock stops.
-        st = r.render_frame(want_stats=stats)
+    def exchange():
+        # the single exchange of a frame.  ptmi_gather_frame only ENQUEUES the RCCL sends/receives and the row placement
+        # (library-owned stream); whatever renders or resolves next waits on the device for the gather that still reads the
+        # tile.  Everything outstanding is drained by barrier() before the clock stops.
         if rccl:
-            r.gather_frame(0, what)                   # the single exchange of a frame
+            r.gather_frame(0, what)
         elif use_dist:
             rgb, rad = r.read_image()
             n = len(rgb)
             fg.send_rgb[:n] = torch.from_numpy(rgb); fg.send_rad[:n] = torch.from_numpy(rad)
             fg.gather()
-        return st
+
+    def run_steps(k, stats, pipelined):
+        # k steps = k successive frames.  Pipelined (ptmi_render_frames): nothing changes between the frames, so a pixel that
+        # has finished frame j goes straight on to frame j + 1 and the stragglers of one frame share the GPU with the head of
+        # the next; every frame's image is then produced (ptmi_select_frame = its resolve pass) and exchanged like a
+        # separately rendered one.  Frame by frame bit-identical to k ptmi_render_frame calls (tests/test_gpu_parity.py).
+        if pipelined and k > 1:
+            st = r.render_frames(k, want_stats=stats)
+            for j in range(k):
+                r.select_frame(j)
+                exchange()
+            return [st]
+        out = []
+        for _ in range(k):
+            out.append(r.render_frame(want_stats=stats))
+            exchange()
+        return out
 
     def barrier():
         if rccl:
@@ -332,33 +348,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    pipelined = args.pipeline
     if args.profile_pass:
         r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=args.segments, collect_stats=False)
-        for _ in range(args.steps):
-            r.render_frame(want_stats=False)
+        run_steps(args.steps, False, pipelined)
         print(json.dumps({"profile_pass": name, "frames": args.steps, **ptmi_buildinfo.stamps()}), flush=True)
         r.close()
         return
 
-    m = measure(r, cfg, args.steps, args.warmup, step, barrier, args.segments, reduce_max)
+    m = measure(r, cfg, args.steps, args.warmup, run_steps, barrier, args.segments, reduce_max, pipelined)
     total_samples = float(cfg["width"]) * cfg["height"] * cfg["spp"] * args.steps if not (cfg["tiling"] and world == 1) \
         else m["local_samples_per_step"] * args.steps
     value = total_samples / m["elapsed"] / 1e6
 
     # the reference's renderFrame() ends with the D2H of the 8-bit image (application.h:211): same steps again with
     # config.download_image (pinned host image); reported next to `value`, which leaves results on the device
-    value_incl_d2h = None
+    value_incl_d2h = value_other = None
     if world == 1 and not use_dist:
         r.set_config(download_image=True)
-        for _ in range(min(args.warmup, 1)):
-            r.render_frame(want_stats=False)
+        run_steps(min(args.warmup, 1), False, pipelined)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.render_frame(want_stats=False)
+        run_steps(args.steps, False, pipelined)
         barrier()
         value_incl_d2h = total_samples / (time.perf_counter() - t0) / 1e6
         r.set_config(download_image=False)
+        if args.steps > 1:                        # the same steps the other way (pipelined batch <-> one call per step), for comparison
+            run_steps(min(args.warmup, 2), False, not pipelined)
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(args.steps, False, not pipelined)
+            barrier()
+            value_other = total_samples / (time.perf_counter() - t0) / 1e6
 
     out = None
     if rank == 0:
@@ -374,6 +395,9 @@ def main():
                        "segments_per_launch": args.segments or "default", "parallelism": f"tile{world}", **m["counters"]},
             "roofline": roofline_block(name, cfg, m, exact),
         }
+        out["config"]["frames"] = "pipelined batch (ptmi_render_frames)" if pipelined and args.steps > 1 else "one ptmi_render_frame call per step"
+        if value_other is not None:
+            out["value_one_call_per_step" if pipelined else "value_pipelined_batch"] = round(value_other, 3)
         if value_incl_d2h is not None:
             out["value_incl_d2h"] = round(value_incl_d2h, 3)
             out["d2h_note"] = "value leaves the frame on the device; value_incl_d2h adds renderFrame()'s 3 B/pixel copy to pinned host memory (application.h:211)"
@@ -381,11 +405,11 @@ def main():
     # N = 1, headline configuration: the other single-GPU workloads of BASELINE.json, driver-timed in the same run
     if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
         extras = []
-        for xname, xsteps in (("c3", 2), ("c5tile", 3)):
+        for xname, xsteps in (("c3", 3), ("c5tile", 6)):
             xcfg = dict(CONFIGS[xname])
             load_scene(r, xcfg["scene"])
             allocate(xcfg)
-            xm = measure(r, xcfg, xsteps, 1, step, barrier, 0, reduce_max)
+            xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps
             tiled = f", rank {xcfg['tiling'][1]} of {xcfg['tiling'][0]}" if xcfg["tiling"] else ""
             extras.append({"name": xname, "workload": f"{xcfg['scene']} {xcfg['width']}x{xcfg['height']}, {xcfg['spp']} spp, max_depth {xcfg['max_depth']}{tiled} ({xcfg['what']})",

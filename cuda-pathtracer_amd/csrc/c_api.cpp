@@ -421,6 +421,22 @@ int ptmi_render_frame(ptmi_ctx* c, ptmi_stats* stats) {
     });
 }
 
+int ptmi_render_frames(ptmi_ctx* c, int n_frames, ptmi_stats* stats) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        FrameStats fs;
+        renderFrames(c->app, n_frames, stats ? &fs : nullptr);
+        if (stats) {
+            stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
+            stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
+            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits;
+        }
+    });
+}
+int ptmi_select_frame(ptmi_ctx* c, int frame) {
+    return guarded([&] { need(c != nullptr, "ctx is NULL"); selectFrame(c->app, frame); });
+}
+
 int ptmi_device_image(const ptmi_ctx* c, void** d_rgb8, void** d_radiance) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");

@@ -100,6 +100,15 @@ struct FrameParams {
     int spp, max_depth;
     int sampling_mode;          // SamplingMode (render_config.h:38-44)
     float mis_bsdf_fraction;    // Scene::mis_bsdf_fraction (scene.h:217)
+    // Frame batches (renderFrames): n_frames successive frames of unchanged scene / camera / config rendered as ONE pipelined
+    // run - a pixel that has finished frame k banks its colour sum in frame_color[k * n_local + slot] and starts frame k + 1 at
+    // once (its RNG stream simply goes on, as between two renderFrame() calls), so the stragglers of frame k share the GPU with
+    // the head of frame k + 1.  The frame index lives above the sample index: sample_idx = frame << 16 | sample (batches need
+    // spp < 65536, n_frames <= 256); a single frame keeps all 24 bits for the sample index (sample_mask 0xffffff).
+    int n_frames = 1;
+    unsigned int sample_mask = 0xffffffu;
+    float4* frame_color = nullptr;     // (n_frames - 1) * n_local colour sums of the completed frames; the last frame's stays in D
+    int n_local = 0;
 };
 
 struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits; };
@@ -124,8 +133,10 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
 // spp camera rays per pixel, first hit only, Le + per-primitive radiosity, sqrt gamma, 8-bit (+ float mean).
 void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                              unsigned char* rgb8, float* radiance, hipStream_t s);
-// mean, Reinhard, gamma, 8-bit (integrator.h:393-407) + float radiance.
-void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s);
+// mean, Reinhard, gamma, 8-bit (integrator.h:393-407) + float radiance.  color_src: the per-slot colour sums to resolve
+// (nullptr = the path state's D array, i.e. the frame just finished; else a slice of FrameParams::frame_color)
+void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s,
+                    const float4* color_src = nullptr);
 
 size_t bounce_lds_bytes(const DeviceScene& sc);
 

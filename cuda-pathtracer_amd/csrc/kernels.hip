@@ -494,9 +494,9 @@ __device__ __forceinline__ void fetch_material(const MatSource& ms, int k, f3& n
         bsdf = xyz(ms.mats[3 * k + 1]); Le = xyz(ms.mats[3 * k + 2]);
     }
 }
-template <bool STATS, bool GUIDED, bool PACKED = false>
+template <bool STATS, bool GUIDED, bool PACKED = false, bool BATCH = false>
 __device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap& tm, const MatSource& ms, const float* cdfs, PathRegs& p,
-                                           bool hit, float t, int k, LaneCounters& cn) {
+                                           bool hit, float t, int k, LaneCounters& cn, int slot) {
     bool end_sample = !hit;                                                       // integrator.h:198-201
     if (hit) {
         if (STATS) cn.hits++;
@@ -555,7 +555,16 @@ __device__ __forceinline__ bool shade_step(const FrameParams& fp, const TileMap&
     if (end_sample) {
         p.color = p.color + p.L;                                                  // integrator.h:390
         p.sample_idx++;
-        if (p.sample_idx >= (unsigned int)fp.spp) return false;
+        if (!BATCH) {
+            if (p.sample_idx >= (unsigned int)fp.spp) return false;
+        } else if ((p.sample_idx & fp.sample_mask) >= (unsigned int)fp.spp) {     // the spp loop of this frame is through
+            const unsigned int frame = p.sample_idx >> 16;
+            if (frame + 1u >= (unsigned int)fp.n_frames) return false;
+            // frame batch: bank this frame's colour sum and go straight on with the next frame's first sample
+            fp.frame_color[frame * (unsigned int)fp.n_local + (unsigned int)slot] = make_float4(p.color.x, p.color.y, p.color.z, 0.0f);   // < 2^31 (host check)
+            p.sample_idx = (frame + 1u) << 16;
+            p.color = mk3(0.0f, 0.0f, 0.0f);
+        }
         camera_ray(fp, tm, p.px, p.py, p.rng, p.o, p.d);                          // next iteration of the spp loop
         p.tp = mk3(1.0f, 1.0f, 1.0f); p.L = mk3(0.0f, 0.0f, 0.0f); p.depth = 0;
     }
@@ -609,8 +618,8 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
 // (MI355X_MICROARCH.md, residency rule); measured +2.4 %, no spills.
 // GUIDED instantiations would take ~100 VGPRs (4 waves per SIMD); capped at 80 (6 waves, 68 bytes of spills): grid
 // sampling +13 %, MIS +9 % on the benchmark frame (5 waves +8 %, 7 the same as 6, 8 waves +10 % / +3 %).
-template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED>
-__global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
+template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool BATCH>
+__global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SWEEP ? 8 : 1)) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_s
         if (STATS && alive) cn.rays++;
         const bool hit = scene_intersect<MODE, HAS_QUADS, STATS>(nodes, prims, a.sc.prim_stride, a.sc.n_nodes, stack, alive,
                                                                p.o, p.d, 1e-4f, FLT_MAX, t, k, cn);
-        if (alive) alive = shade_step<STATS, GUIDED>(a.fp, a.tm, MatSource{mats, nullptr, nullptr}, a.sc.cdfs, p, hit, t, k, cn);
+        if (alive) alive = shade_step<STATS, GUIDED, false, BATCH>(a.fp, a.tm, MatSource{mats, nullptr, nullptr}, a.sc.cdfs, p, hit, t, k, cn, slot);
     }
 
     if (active) store_path(a.st, slot, p);
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : 1) __attribute__((amdgpu_num_s
 #ifndef PTMI_NODE_BURST
 #define PTMI_NODE_BURST 3
 #endif
-template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED = false>
+template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED, bool BATCH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
     extern __shared__ float4 smem[];
     static_assert(!(PACKED && LDS_GEOM), "the packed layout is for scenes that do not fit LDS");
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
             }
         } else {
             if (phase == PH_SHADE) {
-                const bool more = shade_step<STATS, GUIDED, PACKED>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn);
+                const bool more = shade_step<STATS, GUIDED, PACKED, BATCH>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn, slot);
                 segs_left--;
                 if (!more) { alive = false; phase = PH_DONE; }
                 else if (segs_left == 0) phase = PH_DONE;              // state goes back to HBM with the next ray ready
@@ -754,8 +763,13 @@ static bool is_guided(const BounceArgs& a) { return a.fp.sampling_mode != 0 && a
 
 template <int MODE, bool G_, bool Q_, bool S_>
 static void launch_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true>), grid, dim3(kBlock), lds, s, a);
-    else hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false>), grid, dim3(kBlock), lds, s, a);
+    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false, false>), grid, dim3(kBlock), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false, true>), grid, dim3(kBlock), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true, false>), grid, dim3(kBlock), lds, s, a); break;
+        default: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true, true>), grid, dim3(kBlock), lds, s, a); break;
+    }
 }
 template <int MODE, bool G_>
 static void launch_qs(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -774,13 +788,23 @@ static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipSt
 }
 template <bool G_, bool Q_, bool S_>
 static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true>), grid, dim3(kBlock), lds, s, a);
-    else hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false>), grid, dim3(kBlock), lds, s, a);
+    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false, false, false>), grid, dim3(kBlock), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false, false, true>), grid, dim3(kBlock), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true, false, false>), grid, dim3(kBlock), lds, s, a); break;
+        default: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true, false, true>), grid, dim3(kBlock), lds, s, a); break;
+    }
 }
 template <bool Q_, bool S_>
 static void launch_packed_one(const BounceArgs& a, dim3 grid, hipStream_t s) {
-    if (is_guided(a)) hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true>), grid, dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true>), grid, dim3(kBlock), 0, s, a);
+    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
+    switch (key) {
+        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, false>), grid, dim3(kBlock), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, true>), grid, dim3(kBlock), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, false>), grid, dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, true>), grid, dim3(kBlock), 0, s, a); break;
+    }
 }
 static void launch_packed(const BounceArgs& a, dim3 grid, hipStream_t s) {
 
@@ -834,11 +858,11 @@ void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParam
 // resolve: color /= spp; Reinhard; gamma 1/2.2; 8-bit (integrator.h:393-407)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void ptmi_resolve(TileMap tm, PathState st, int spp, unsigned char* __restrict__ rgb8,
-                                                       float* __restrict__ radiance) {
+                                                       float* __restrict__ radiance, const float4* __restrict__ color_src) {
     const int n = tm.local_rows * tm.width;
     const int slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= n) return;
-    const float4 D = st.D[slot];
+    const float4 D = color_src ? color_src[slot] : st.D[slot];
     int ox, olr;
     slot_to_local(tm, slot, ox, olr);
     const size_t out = (size_t)olr * (size_t)tm.width + (size_t)ox;      // images are local-row-major whatever the slot order
@@ -856,10 +880,11 @@ __global__ __launch_bounds__(kBlock) void ptmi_resolve(TileMap tm, PathState st,
     }
 }
 
-void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s) {
+void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned char* rgb8, float* radiance, hipStream_t s,
+                    const float4* color_src) {
     const int n = tm.local_rows * tm.width;
     if (n <= 0) return;
-    hipLaunchKernelGGL(ptmi_resolve, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, spp, rgb8, radiance);
+    hipLaunchKernelGGL(ptmi_resolve, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, spp, rgb8, radiance, color_src);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -499,8 +499,9 @@ void SceneState::chooseTraversal() {
 // RenderState
 // ------------------------------------------------------------------------------------------------
 void RenderState::freeBuffers() {
-    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats};
+    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats, d_frame_color};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_frame_color = nullptr; frame_color_frames = 0; batch_frames = 1; batch_spp = 0;
     if (h_image) { (void)hipHostFree(h_image); h_image = nullptr; }
     for (Chunk& c : chunk) {
         void* cp[] = {c.d_queue_init, c.d_queue[0], c.d_queue[1], c.d_count};
@@ -605,8 +606,29 @@ ApplicationState::~ApplicationState() {
     for (RenderState::Chunk& c : render.chunk) if (c.stream) (void)hipStreamDestroy(c.stream);
 }
 
-void renderFrame(ApplicationState& g, FrameStats* stats) {
+void renderFrame(ApplicationState& g, FrameStats* stats) { renderFrames(g, 1, stats); }
+
+void selectFrame(ApplicationState& g, int frame) {
     RenderState& r = g.render;
+    if (!r.d_state.A || r.batch_spp <= 0) throw ArgError("selectFrame: nothing rendered yet");
+    if (frame < 0 || frame >= r.batch_frames) throw ArgError("selectFrame: frame index outside the last batch");
+    PTMI_HIP(hipSetDevice(g.device_id));
+    if (r.resolve_gate) PTMI_HIP(hipStreamWaitEvent(r.stream, r.resolve_gate, 0));
+    const float4* src = frame == r.batch_frames - 1 ? nullptr : r.d_frame_color + (size_t)frame * r.n_local;
+    launch_resolve(r.tile, r.d_state, r.batch_spp, r.d_image, r.d_radiance, r.stream, src);
+    PTMI_HIP(hipGetLastError());
+    if (r.download_image && r.n_local) PTMI_HIP(hipMemcpyAsync(r.h_image, r.d_image, r.n_local * 3, hipMemcpyDeviceToHost, r.stream));
+    PTMI_HIP(hipStreamSynchronize(r.stream));
+}
+
+void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
+    RenderState& r = g.render;
+    if (n_frames < 1 || n_frames > 256) throw ArgError("renderFrames: n_frames must be in [1, 256]");
+    if (n_frames > 1 && g.config.spp >= (1 << 16)) throw ArgError("renderFrames: a batch needs spp < 65536");
+    if (n_frames > 1 && (unsigned long long)(n_frames - 1) * r.n_local >= (1ull << 31))
+        throw ArgError("renderFrames: (n_frames - 1) * local pixels must stay below 2^31");
+    if (n_frames > 1 && g.config.current_integrator == IntegratorType::Radiosity)
+        throw ArgError("renderFrames: the Radiosity integrator renders one frame per call");
     if (!g.scene.d_nodes) throw ArgError("renderFrame: no scene loaded");
     if (!r.d_state.A) throw ArgError("renderFrame: buffers not allocated (call updateResolution first)");
     if (g.config.spp < 1 || g.config.spp >= (1 << 24)) throw ArgError("spp must be in [1, 2^24)");
@@ -622,6 +644,16 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
     for (int i = 0; i < 4; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
     fp.spp = g.config.spp; fp.max_depth = g.config.max_depth;
     fp.sampling_mode = (int)g.config.sampling_mode; fp.mis_bsdf_fraction = g.config.mis_bsdf_fraction;
+    PTMI_HIP(hipSetDevice(g.device_id));
+    if (n_frames > 1) {
+        if (r.frame_color_frames < (size_t)(n_frames - 1)) {
+            if (r.d_frame_color) { (void)hipFree(r.d_frame_color); r.d_frame_color = nullptr; r.frame_color_frames = 0; }
+            r.d_frame_color = (float4*)hipMallocSafe((size_t)(n_frames - 1) * std::max<size_t>(r.n_local, 1) * sizeof(float4), "d_frame_color");
+            r.frame_color_frames = (size_t)(n_frames - 1);
+        }
+        fp.n_frames = n_frames; fp.sample_mask = 0xffffu; fp.frame_color = r.d_frame_color; fp.n_local = (int)r.n_local;
+    }
+    r.batch_frames = n_frames; r.batch_spp = g.config.spp;
 
     const int n_local = (int)r.n_local;
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
@@ -747,7 +779,7 @@ void renderFrame(ApplicationState& g, FrameStats* stats) {
         stats->bounce_kernel_ms = kms;
         stats->bounce_launches = launches;
         stats->path_visits = visits;
-        stats->samples = (uint64_t)n_local * (uint64_t)g.config.spp;
+        stats->samples = (uint64_t)n_local * (uint64_t)g.config.spp * (uint64_t)n_frames;
         if (want_stats) {
             StatCounters c;
             PTMI_HIP(hipMemcpy(&c, r.d_stats, sizeof c, hipMemcpyDeviceToHost));

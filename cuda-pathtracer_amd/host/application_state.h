@@ -139,6 +139,10 @@ struct RenderState {
     unsigned char* h_image = nullptr;                // RGB8, local rows, PINNED: RenderState::h_image (application_state.h:77, 99);
                                                      // renderFrame() ends with the D2H into it (application.h:211) when download_image
     bool download_image = false;
+    // frame batches (renderFrames): colour sums of the batch's completed frames, (n_frames - 1) * n_local float4
+    float4* d_frame_color = nullptr;
+    size_t frame_color_frames = 0;                   // capacity in frames
+    int batch_frames = 1, batch_spp = 0;             // what the last render call produced (selectFrame)
     hipEvent_t resolve_gate = nullptr;               // not owned: while set, the next resolve waits for it (a frame gather still
                                                      // reading this rank's tile, csrc/dist.hip)
     // The local pixels are dealt to kMaxChunks independent queues (256-slot blocks, round-robin), each driven through
@@ -219,6 +223,11 @@ struct ApplicationState {
 
 // renderFrame — application.h:157-216: camera update, launches, device sync.  Results stay on the device.
 void renderFrame(ApplicationState& g_state, FrameStats* stats);
+// n_frames successive renderFrame() calls with nothing changed in between, as one pipelined run (device_scene.h:
+// FrameParams::n_frames).  Frame by frame the images are bit-identical to n_frames separate calls; afterwards the image
+// buffers hold the LAST frame and selectFrame(j) resolves any frame of the batch into them.
+void renderFrames(ApplicationState& g_state, int n_frames, FrameStats* stats);
+void selectFrame(ApplicationState& g_state, int frame);
 
 // GF(2) matrices T^(2^67 * 2^k), k = 0..31, of the xorwow state transition (cuRAND's subsequence skip-ahead).
 std::vector<uint32_t> buildXorwowJumpMatrices();

@@ -27,7 +27,7 @@ EXPORTS = [
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
-    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes",
+    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_render_frames", "ptmi_select_frame",
 ]
 
 
@@ -99,6 +99,8 @@ def lib():
         L.ptmi_local_rows.argtypes = [vp, ip]
         L.ptmi_local_row_map.argtypes = [vp, vp]
         L.ptmi_render_frame.argtypes = [vp, C.POINTER(Stats)]
+        L.ptmi_render_frames.argtypes = [vp, C.c_int, C.POINTER(Stats)]
+        L.ptmi_select_frame.argtypes = [vp, C.c_int]
         L.ptmi_device_image.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.ptmi_read_image.argtypes = [vp, vp, vp]
         L.ptmi_copy_image_device.argtypes = [vp, vp, vp]
@@ -379,6 +381,15 @@ class Renderer:
         st = Stats()
         self._ck(self.L.ptmi_render_frame(self.h, C.byref(st) if want_stats else None))
         return st
+
+    def render_frames(self, n_frames, want_stats=True):
+        """n_frames successive frames as one pipelined run (ptmi_render_frames); the image buffers then hold the last one."""
+        st = Stats()
+        self._ck(self.L.ptmi_render_frames(self.h, int(n_frames), C.byref(st) if want_stats else None))
+        return st
+
+    def select_frame(self, frame):
+        self._ck(self.L.ptmi_select_frame(self.h, int(frame)))
 
     def device_image(self):
         a = C.c_void_p(); b = C.c_void_p()

@@ -208,6 +208,16 @@ int ptmi_local_row_map(const ptmi_ctx*, int* rows_out);
  * device.  Asynchronous work is complete when it returns. */
 int ptmi_render_frame(ptmi_ctx*, ptmi_stats* stats /* may be NULL */);
 
+/* n_frames successive ptmi_render_frame calls with nothing changed in between (scene, camera, config), as ONE pipelined run:
+ * a pixel that has finished frame k starts frame k + 1 at once - its RNG stream goes on exactly as it does between two
+ * renderFrame() calls - so the few long-running pixels at the end of frame k share the GPU with the head of frame k + 1
+ * instead of leaving it idle.  Frame by frame the images are bit-identical to n_frames separate calls.  Afterwards the image
+ * buffers hold the LAST frame (what n calls would leave); ptmi_select_frame(j) puts frame j of the batch there instead
+ * (then ptmi_read_image / ptmi_gather_frame / ptmi_host_image as usual).  n_frames in [1, 256]; a batch of more than one frame
+ * needs spp < 65536 and the PathTracing integrator.  stats cover the whole batch. */
+int ptmi_render_frames(ptmi_ctx*, int n_frames, ptmi_stats* stats /* may be NULL */);
+int ptmi_select_frame(ptmi_ctx*, int frame /* 0 .. n_frames-1 of the last ptmi_render_frame(s) call */);
+
 /* Results.  Both images hold this rank's rows only, local row-major
  * (local_rows x width x 3); local row r is global row ptmi_local_row_map()[r];
  * row 0 of the frame is the BOTTOM row (v = y/H from the lower-left corner,

@@ -114,7 +114,7 @@ def test_bench_line_carries_every_contract_field():
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0.0 < d["roofline"]["frac"] <= 1.0          # a fraction of the peak, never above it
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert "profile_stale" in d["roofline"] and "algorithmic_GBps" in d["roofline"] and "served_from" in d["roofline"]
-    assert d["value_incl_d2h"] > 0
+    assert d["value_incl_d2h"] > 0 and d["config"]["frames"].startswith("one ptmi_render_frame call per step")
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1

@@ -334,6 +334,47 @@ def test_rng_state_persists_across_frames(R):
     assert (bits(rad0) == bits(orad0)).all()
 
 
+@pytest.mark.parametrize("name,sub,W,H,spp,depth,n", [("cbox.obj", 0, 96, 64, 5, 6, 4), ("cbox_quads.obj", 0, 50, 31, 3, 5, 3),
+                                                      ("cbox.obj", 2, 64, 48, 4, 5, 3), ("cbox.obj", 3, 64, 40, 3, 6, 5)])
+def test_frame_batch_equals_successive_frames(R, name, sub, W, H, spp, depth, n):
+    """ptmi_render_frames(n): pixels go from frame k straight on to frame k + 1 (pipelined), every frame of the batch must be
+    bit-identical to the k-th of n separate ptmi_render_frame calls and to the oracle's k-th frame; the RNG streams afterwards
+    stand where n separate calls leave them (one more frame compared)."""
+    path = os.path.join(SCENES, name)
+    R.load_scene(path, sub)
+    if sub == 3:
+        R.set_packed_min_nodes(16)
+    o = OracleScene.load(path, sub)
+    state = np.zeros((H * W, 6), np.uint32)
+    want = []
+    for k in range(n + 1):
+        orgb, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, rng_state=state, reset_rng=(k == 0))
+        want.append((orgb.copy(), orad.copy()))
+    try:
+        for seg in (0, 2):
+            R.update_resolution(W, H)
+            R.set_config(spp=spp, max_depth=depth, segments_per_launch=seg, collect_stats=False)
+            st = R.render_frames(n)
+            assert st.samples == W * H * spp * n
+            assert_same_image(*R.read_image(), *want[n - 1], "last frame of the batch")
+            for k in (0, n - 1, 1, n - 2):
+                R.select_frame(k)
+                assert_same_image(*R.read_image(), *want[k], f"{name} frame {k} of {n} seg {seg}")
+            with pytest.raises(ptmi.PtmiError):
+                R.select_frame(n)
+            R.render_frame()                                        # streams carried on across the batch
+            assert_same_image(*R.read_image(), *want[n], "frame after the batch")
+            R.select_frame(0)
+            assert_same_image(*R.read_image(), *want[n], "a single frame is a batch of one")
+        with pytest.raises(ptmi.PtmiError):
+            R.render_frames(0)
+        R.set_config(spp=65536)
+        with pytest.raises(ptmi.PtmiError):
+            R.render_frames(2)
+    finally:
+        R.set_config(spp=1, segments_per_launch=0); R.set_packed_min_nodes(8192)
+
+
 def test_camera_and_seed_parameters(R):
     cam = ptmi.Camera((0.5, 3.0, 8.5), (0, 2.5, 0), (0, 1, 0), 55.0, 70.0, 10.0, 1)
     path = os.path.join(SCENES, "cbox_quads.obj")
