@@ -112,10 +112,13 @@ void SceneState::loadSceneHost(const std::string& filename, int subdivision_coun
     if (dot == std::string::npos) throw IoError("unsupported file format (no extension): " + filename);
     std::string ext = filename.substr(dot);
     std::transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char c) { return (char)std::tolower(c); });
-    if (ext != ".obj") throw IoError("unsupported file format: " + ext);          // .pbrt is out of scope (USE_PBRT_LOADER off)
-
     std::vector<Primitive> prims;
-    if (!loadOBJ(filename, prims)) throw IoError("failed to load scene: " + filename);
+    if (ext == ".obj") {
+        if (!loadOBJ(filename, prims)) throw IoError("failed to load scene: " + filename);
+    } else if (ext == ".pbrt") {                                                    // USE_PBRT_LOADER, application_state.h:385-388
+        std::string why;
+        if (!loadPBRT(filename, prims, &why)) throw IoError("failed to load scene: " + filename + " (" + why + ")");
+    } else throw IoError("unsupported file format: " + ext);
     if (convert_quads) prims = convertQuadsToTriangles(prims);
     if (subdivision_count > 0) prims = subdivide_primitives(prims, subdivision_count);
     h_primitives.swap(prims);

@@ -17,6 +17,7 @@
 #include "../csrc/device_scene.h"
 #include "bvh.h"
 #include "file_manager.h"
+#include "pbrt_loader.h"
 #include "sensor.h"
 
 namespace ptmi {

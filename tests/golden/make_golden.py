@@ -57,3 +57,19 @@ for scene, sub, prm in SOLVER_CASES:
                         radiosity_grid=sol["radiosity_grid"], rays=np.uint64(sol["rays"]), cdfs=o.cdfs(),
                         guided_rgb8=g_rgb, guided_radiance=g_rad, view_rgb8=v_rgb, view_radiance=v_rad)
     print(name, float(sol["form_factors"].sum()), float(sol["radiosity"].mean()), sol["rays"])
+
+
+# PBRT import: the primitive arrays the REFERENCE's own loadPBRT (utils/pbrt_loader.h:178-422, compiled with the
+# vendored pbrtParser into oracle/_ref/libptmi_ref_pbrt.so by oracle/Makefile) returns for the fixtures under golden/pbrt/.
+# Only where /root/reference exists; the .npz files travel.  A fixture the reference rejects gets failed = True.
+from oracle_binding import ref_pbrt_available, ref_pbrt_load  # noqa: E402
+import glob  # noqa: E402
+if ref_pbrt_available():
+    for f in sorted(glob.glob(os.path.join(HERE, "pbrt", "*.pbrt"))):
+        got = ref_pbrt_load(f)
+        out = os.path.splitext(f)[0] + ".npz"
+        if got is None:
+            np.savez_compressed(out, failed=True)
+        else:
+            np.savez_compressed(out, failed=False, **got)
+        print(os.path.basename(out), "rejected" if got is None else len(got["type"]))

@@ -372,3 +372,32 @@ def ref_camera(cam, width, height):
     ref_lib().ref_camera(lf.ctypes.data, la.ctypes.data, up.ctypes.data, cam.vfov_deg, cam.yaw_deg, cam.pitch_deg,
                          cam.orbit, width, height, out.ctypes.data)
     return out
+
+
+# ---- the reference's PBRT import, compiled (oracle/_ref/libptmi_ref_pbrt.so) -------------------------------------------------
+REF_PBRT_SO = os.path.join(os.path.dirname(REF_SO), "libptmi_ref_pbrt.so")
+_ref_pbrt = None
+
+
+def ref_pbrt_available():
+    return os.path.exists(REF_PBRT_SO)
+
+
+def ref_pbrt_load(path):
+    """loadPBRT of the reference on `path`: dict(type, verts, normal, bsdf, Le) or None where it fails (returns false / throws)."""
+    global _ref_pbrt
+    if _ref_pbrt is None:
+        L = C.CDLL(REF_PBRT_SO)
+        L.ref_pbrt_load.restype = C.c_void_p; L.ref_pbrt_load.argtypes = [C.c_char_p, C.c_int]
+        L.ref_pbrt_count.argtypes = [C.c_void_p]; L.ref_pbrt_get.argtypes = [C.c_void_p] * 6; L.ref_pbrt_free.argtypes = [C.c_void_p]
+        _ref_pbrt = L
+    L = _ref_pbrt
+    h = L.ref_pbrt_load(os.fsencode(os.path.abspath(path)), 1)
+    if not h:
+        return None
+    n = L.ref_pbrt_count(h)
+    t = np.zeros(n, np.int32); v = np.zeros((n, 4, 3), np.float32)
+    nr = np.zeros((n, 3), np.float32); b = np.zeros((n, 3), np.float32); le = np.zeros((n, 3), np.float32)
+    L.ref_pbrt_get(h, t.ctypes.data, v.ctypes.data, nr.ctypes.data, b.ctypes.data, le.ctypes.data)
+    L.ref_pbrt_free(h)
+    return dict(type=t, verts=v, normal=nr, bsdf=b, Le=le)

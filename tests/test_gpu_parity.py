@@ -375,6 +375,35 @@ def test_frame_batch_equals_successive_frames(R, name, sub, W, H, spp, depth, n)
         R.set_config(spp=1, segments_per_launch=0); R.set_packed_min_nodes(8192)
 
 
+@pytest.mark.parametrize("name,sub", [("05_instances.pbrt", 0), ("03_arealight.pbrt", 1), ("04_materials.pbrt", 0)])
+def test_pbrt_scene_renders_like_the_oracle_on_the_same_primitives(R, name, sub):
+    """ptmi_load_scene on a .pbrt file (own parser, pinned against the compiled reference importer in
+    tests/test_pbrt_loader.py), then the ordinary path: the frame must equal the oracle's on the golden primitive arrays."""
+    path = os.path.join(GOLDEN, "pbrt", name)
+    g = np.load(os.path.splitext(path)[0] + ".npz")
+    R.load_scene(path, sub)
+    p = R.scene_prims()
+    if sub == 0:
+        for k in ("verts", "normal", "bsdf", "Le"):
+            assert (bits(p[k]) == bits(g[k])).all(), k
+    else:
+        assert len(p["type"]) == len(g["type"]) * 4 ** sub             # subdivide_primitives after the import, as for OBJ scenes
+    o = OracleScene.from_arrays(p["type"], p["verts"], p["normal"], p["bsdf"], p["Le"])
+    cam = ptmi.default_camera(); cam.origin[:] = (3.0, 2.5, 14.0); cam.lookat[:] = (0.5, 0.5, 6.0); cam.orbit = 0
+    R.set_camera(cam)
+    W, H, spp = 72, 48, 6
+    R.update_resolution(W, H); R.set_config(spp=spp, max_depth=5, collect_stats=True)
+    try:
+        st = R.render_frame()
+        rgb, rad = R.read_image()
+        orgb, orad, ost = o.render(ocam_of(cam), W, H, spp, max_depth=5)
+        assert_same_image(rgb, rad, orgb, orad, name)
+        assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        assert st.hits > 0
+    finally:
+        R.set_camera(ptmi.default_camera()); R.set_config(collect_stats=False)
+
+
 def test_camera_and_seed_parameters(R):
     cam = ptmi.Camera((0.5, 3.0, 8.5), (0, 2.5, 0), (0, 1, 0), 55.0, 70.0, 10.0, 1)
     path = os.path.join(SCENES, "cbox_quads.obj")
