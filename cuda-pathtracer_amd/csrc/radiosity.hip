@@ -412,6 +412,107 @@ __global__ __launch_bounds__(kIterBlock) void ptmi_radiosity_iterate(RadiosityBu
     rb.unshot[1 - src][i] = make_float4(reflected.x, reflected.y, reflected.z, 0.0f);
 }
 
+
+// ---- ptmi_radiosity_iterate_tiled: the same step as an HBM stream ----------------------------------------------------------
+// The Jacobi step reads the n x n form-factor matrix once (4 n^2 bytes: 268 MB at n = 8192) and does 6 flops per entry,
+// so its roofline is HBM bandwidth; what holds it back is that every row's sum is ONE sequential float chain (ascending j -
+// the reference's order, form_factors.h:452-459, which fixes the bits).  With a lane per row (the kernel above) a wave reads
+// 64 rows at a 4n-byte stride - 64 cache lines per load instruction - and its chain costs 11 instructions per j.
+// Here a 64-thread workgroup owns R = 8 (or 16) rows:
+//   * loading: one global_load_dwordx4 per lane covers 256 consecutive floats of ONE row (1 KiB, fully coalesced); R of
+//     them are an R x 256 tile, issued for tile t + 1 before tile t is consumed (R KiB in flight per wave), staged in LDS
+//     with a row stride of 260 floats (the lanes of a 16-lane group then read different rows from different banks);
+//   * summing: lane = channel * R + row, i.e. the three colour channels of a row are three lanes, each with ONE running
+//     sum.  F is read from LDS as a broadcast to the row's three lanes, the unshot radiosity as a per-channel (SoA)
+//     broadcast to a channel's sixteen.  Entries the reference skips (`j != i && F_ij > 0.0f` false: the diagonal, F <= 0,
+//     columns past n) are stored as +0 in the tile, and adding 0 * u_j changes nothing while u_j is finite - so per j the
+//     chain is one multiply and one add (the lane-per-row kernel: 3 + 3 + 3 selects + 2 compares); a tile holding a
+//     non-finite unshot value takes the compare / select form.  Same sums in the same order: bit-identical to the kernel
+//     above and to the oracle.
+constexpr int kTileCols = 256, kTileStride = kTileCols + 4, kUStride = kTileCols / 4 + 1;
+template <int kTileRows>
+__global__ __launch_bounds__(64) void ptmi_radiosity_iterate_tiled(RadiosityBuffers rb, int src) {
+    __shared__ float4 f_lds[kTileRows * kTileStride / 4];
+    __shared__ float4 u_lds[4][kUStride];                             // [channel][column], channels on different banks
+    const int n = rb.n, lane = threadIdx.x;
+    const int row0 = blockIdx.x * kTileRows;
+    const int ch = lane / kTileRows, r = lane % kTileRows, i = row0 + r;   // the lane's running sum: channel ch (>= 3: none) of row i
+    const float* __restrict__ F = rb.form_factors;
+    const float4* __restrict__ unshot = rb.unshot[src];
+    const int n_tiles = (n + kTileCols - 1) / kTileCols;
+    float4 fr[kTileRows], ur[4];
+    auto issue = [&](int t) {                                         // tile t -> registers (n % 4 == 0: a float4 never straddles n)
+        const int col = t * kTileCols + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < kTileRows; k++) {
+            const int rk = min(row0 + k, n - 1);
+            fr[k] = col < n ? *reinterpret_cast<const float4*>(F + (size_t)rk * (size_t)n + col) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = t * kTileCols + lane + 64 * c;
+            ur[c] = j < n ? unshot[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    bool u_finite = true;                                             // wave-uniform: every unshot value of the tile is finite
+    auto commit = [&](int t) {                                        // registers -> LDS
+        // entries the reference skips (F_ij <= 0, or NaN) become +0: with a finite u_j, `sum + 0 * u_j` leaves the running sum
+        // as it is (it is never -0: it starts at +0), so the chain below needs no compare / select per entry
+#pragma unroll
+        for (int k = 0; k < kTileRows; k++)
+            f_lds[(k * kTileStride) / 4 + lane] = make_float4(fmaxf(fr[k].x, 0.0f), fmaxf(fr[k].y, 0.0f), fmaxf(fr[k].z, 0.0f), fmaxf(fr[k].w, 0.0f));
+        bool fin = true;
+#pragma unroll
+        for (int c = 0; c < 4; c++) fin = fin && isfinite(ur[c].x) && isfinite(ur[c].y) && isfinite(ur[c].z);
+        u_finite = __all(fin);
+        float* us = reinterpret_cast<float*>(u_lds);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int jl = lane + 64 * c;
+            us[0 * 4 * kUStride + jl] = ur[c].x; us[1 * 4 * kUStride + jl] = ur[c].y; us[2 * 4 * kUStride + jl] = ur[c].z; us[3 * 4 * kUStride + jl] = 0.0f;
+        }
+        __syncthreads();
+        const int d = i - t * kTileCols;                              // the diagonal entry of row i, if it lies in this tile
+        if (ch == 0 && d >= 0 && d < kTileCols) reinterpret_cast<float*>(f_lds)[r * kTileStride + d] = 0.0f;
+        __syncthreads();
+    };
+    float acc = 0.0f;
+    issue(0);
+    for (int t = 0; t < n_tiles; t++) {
+        commit(t);
+        if (t + 1 < n_tiles) issue(t + 1);
+        const float4* frow = f_lds + (r * kTileStride) / 4;
+        const float4* urow = u_lds[min(ch, 3)];
+        if (u_finite) {
+#pragma unroll 8
+            for (int q = 0; q < kTileCols / 4; q++) {
+                const float4 f4 = frow[q], u4 = urow[q];
+                acc = acc + f4.x * u4.x; acc = acc + f4.y * u4.y; acc = acc + f4.z * u4.z; acc = acc + f4.w * u4.w;
+            }
+        } else {                                                      // an infinite or NaN unshot value: 0 * u_j would not be 0
+#pragma unroll 4
+            for (int q = 0; q < kTileCols / 4; q++) {
+                const float4 f4 = frow[q], u4 = urow[q];
+                float tsum;
+                tsum = acc + f4.x * u4.x; acc = f4.x > 0.0f ? tsum : acc;
+                tsum = acc + f4.y * u4.y; acc = f4.y > 0.0f ? tsum : acc;
+                tsum = acc + f4.z * u4.z; acc = f4.z > 0.0f ? tsum : acc;
+                tsum = acc + f4.w * u4.w; acc = f4.w > 0.0f ? tsum : acc;
+            }
+        }
+        __syncthreads();                                              // the tile is consumed before commit(t + 1) overwrites it
+    }
+    if (i >= n) return;
+    float* rad = reinterpret_cast<float*>(rb.radiosity + i);
+    float* out = reinterpret_cast<float*>(rb.unshot[1 - src] + i);
+    if (ch > 3) return;
+    if (ch == 3) { out[3] = 0.0f; return; }
+    const float bsdf = reinterpret_cast<const float*>(rb.bsdf + i)[ch];
+    const float reflected = fminf(bsdf * acc, acc);
+    rad[ch] = rad[ch] + reflected;
+    out[ch] = reflected;
+}
+
 // grid_filter.h:35-41, 55-101 (bilateral), 221-249 (gaussian)
 __device__ __forceinline__ float gaussian_weight(float distance, float sigma) { return ptmi_expf(-(distance * distance) / (2.0f * sigma * sigma)); }
 __device__ __forceinline__ float luminance_from_rgb(f3 rgb) { return 0.2126f * rgb.x + 0.7152f * rgb.y + 0.0722f * rgb.z; }
@@ -602,7 +703,16 @@ void launch_form_factors(const DeviceScene& sc, const RadiosityBuffers& rb, cons
 
 void launch_radiosity_iteration(const RadiosityBuffers& rb, int src, hipStream_t s) {
     if (rb.n <= 0) return;
-    hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kIterBlock - 1) / kIterBlock), dim3(kIterBlock), 0, s, rb, src);
+    static const bool force_rows = getenv("PTMI_RADIOSITY_ROWS") != nullptr;        // A/B knob: the lane-per-row kernel
+    // rows per 64-thread workgroup: 8 (24 summing lanes, n / 8 waves: 4 per CU at n = 8192) measured 83 us per step at n = 8192
+    // against 91 us with 16 (48 summing lanes, 2 waves per CU): more waves, more row data in flight
+    static const int tile_rows = getenv("PTMI_RADIOSITY_TILE_ROWS") ? atoi(getenv("PTMI_RADIOSITY_TILE_ROWS")) : 8;
+    if ((rb.n & 3) == 0 && rb.n >= 64 && !force_rows) {                              // rows are 16-byte aligned only if n % 4 == 0
+        if (tile_rows == 16) hipLaunchKernelGGL(ptmi_radiosity_iterate_tiled<16>, dim3((rb.n + 15) / 16), dim3(64), 0, s, rb, src);
+        else hipLaunchKernelGGL(ptmi_radiosity_iterate_tiled<8>, dim3((rb.n + 7) / 8), dim3(64), 0, s, rb, src);
+    }
+    else
+        hipLaunchKernelGGL(ptmi_radiosity_iterate, dim3((rb.n + kIterBlock - 1) / kIterBlock), dim3(kIterBlock), 0, s, rb, src);
 }
 
 void launch_cdf_records(int n, const void* d_src, int src_kind, float* d_out, hipStream_t s) {
