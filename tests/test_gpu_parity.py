@@ -690,3 +690,24 @@ def test_whole_path_from_plain_c(R, tmp_path):
     mean = float(rad.astype(np.float64).sum() / rad.size)
     assert f"mean radiance {mean:.6f}" in out.stdout, (mean, out.stdout)
     R.set_config(sampling_mode=0)
+
+
+def test_tiled_frame_from_plain_c_through_rccl(R, tmp_path):
+    """examples/render_tiled.c (C99): ptmi_dist_unique_id / ptmi_dist_init / ptmi_gather_frame / ptmi_read_frame - the multi-GPU
+    path of a C caller - with the one rank a one-GPU box allows; the frame it writes is the Python binding's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "cuda-pathtracer_amd")
+    exe = tmp_path / "render_tiled"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "render_tiled.c"),
+                           "-L" + libdir, "-lptmi", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    png = tmp_path / "t.png"
+    out = subprocess.run([str(exe), os.path.join(SCENES, "cbox.obj"), "1", "0", str(tmp_path / "id"), str(png), "96", "64", "4"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    R.load_scene(os.path.join(SCENES, "cbox.obj"))
+    R.update_resolution(96, 64); R.set_config(spp=4, max_depth=5)
+    R.render_frame()
+    rgb, _ = R.read_image()
+    assert f"byte sum {int(rgb.astype(np.uint64).sum())}" in out.stdout, out.stdout
+    assert png.stat().st_size > 96 * 64 * 3
