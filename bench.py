@@ -46,6 +46,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9             # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
 PROFILE_ROUND = "r02"
+# tools/gather_rate.hip on this GPU (profiles/r02_gather_rate.txt): dependent random fetches of 32-byte records, 28 active lanes
+# per wave, ~50 VALU instructions between fetches - 2.20e11 /s from a 20 MB table, 1.84e11 /s from a 120 MB one, the same at 3 and
+# at 8 waves per SIMD: the ceiling the large-scene walk runs against (its records: 20 MB of nodes, 36 MB of triangles, 16 MB of
+# material records)
+GATHER_PEAK_RECORDS_PER_S = 2.0e11
 
 CONFIGS = {
     "c2": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce",
@@ -197,6 +202,13 @@ def roofline_block(name, cfg, m, exact_workload):
                            "issue_frac_guide_2clk": round(2.0 / clk, 4),
                            # this repo's microbenchmark (tools/valu_rate*.hip): 2.4 clocks for an all-full-rate stream
                            "issue_frac_measured_floor_2p4clk": round(2.4 / clk, 4)}
+    if cfg["served_from"] != "lds":
+        # the large-scene walk is a stream of dependent per-lane record fetches (one node, triangle or material record each):
+        # its ceiling is the chip's random-fetch rate, measured with tools/gather_rate.hip, not a byte rate
+        fetches = m["record_fetches_per_step"] / step_s
+        out["gather"] = {"record_fetches_per_s": round(fetches, 1), "peak_measured": GATHER_PEAK_RECORDS_PER_S,
+                         "frac": round(fetches / GATHER_PEAK_RECORDS_PER_S, 4),
+                         "what": "node visits + primitive tests + material fetches per second vs tools/gather_rate.hip (profiles/r02_gather_rate.txt)"}
     out["note"] = ("achieved = HBM bytes per step / step time, frac <= 1 by construction; algorithmic_* follow SURVEY 8(d) and count "
                    "node/triangle/material reads, which are served from " + cfg["served_from"])
     return out
@@ -223,6 +235,7 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     return dict(elapsed=elapsed, steps=steps, kernel_ms=kernel_ms, launches=launches, visits=visits, frame_dev_s=frame_dev_s,
                 bytes_per_sample=bytes_per_sample, local_samples_per_step=float(n_local_px) * cfg["spp"],
                 streams=r.config.streams or (2 if n_local_px >= (1 << 18) else 1),
+                record_fetches_per_step=float(st_counts.node_visits + st_counts.prim_tests + st_counts.hits),
                 counters=dict(rays_per_sample=round(st_counts.rays / st_counts.samples, 3),
                               nodes_per_ray=round(st_counts.node_visits / st_counts.rays, 2),
                               tests_per_ray=round(st_counts.prim_tests / st_counts.rays, 2)))

@@ -574,6 +574,19 @@ int ptmi_debug_set_packed_min_nodes(ptmi_ctx* c, int min_nodes, int* n_positions
     });
 }
 
+int ptmi_debug_set_packed_top(ptmi_ctx* c, int top_records, int* n_top, int* top_depth) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(top_records >= 0 && top_records <= 2048, "top_records must be in [0, 2048] (64 KB of LDS)");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        SceneState& s = c->app.scene;
+        s.packed_top_records = top_records;
+        if (s.d_nodes) { s.buildPacked(); s.chooseTraversal(); }
+        if (n_top) *n_top = s.d_scene.n_top;
+        if (top_depth) *top_depth = s.d_scene.top_depth;
+    });
+}
+
 int ptmi_debug_intersect(ptmi_ctx* c, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm) {
     return guarded([&] {

@@ -57,6 +57,7 @@ struct DeviceScene {
     const float4* gmats = nullptr;     // (normal.xyz, bits(row of mtab)) per leaf-order slot
     const float4* mtab = nullptr;      // distinct (Kd, Ke) pairs, 2 float4 per row
     const int* load_index = nullptr;   // leaf-order slot -> load-order primitive index (guided sampling reads cdfs through it)
+    int n_top = 0, top_depth = 0;      // positions < n_top (the nodes of depth <= top_depth, level by level) are staged into LDS
 };
 // PACKED LAYOUT.  On the 1 M-triangle scene the phased walk is bound by the rate at which L2 misses are served (it runs at
 // the same speed with 2 and with 7 waves per SIMD, with and without half of its node reads moved to LDS): what counts is the

@@ -670,6 +670,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     const float4 *nodes, *prims, *mats;
     stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
     if (PACKED) nodes = a.sc.gnodes;
+    const int n_top = PACKED ? a.sc.n_top : 0;           // the top of the packed tree, staged into LDS (device_scene.h)
+    if (PACKED && n_top) {
+        for (int i = threadIdx.x; i < 2 * n_top; i += kBlock) smem[i] = a.sc.gnodes[i];
+        __syncthreads();
+    }
     const MatSource ms = PACKED ? MatSource{a.sc.gmats, a.sc.mtab, a.sc.load_index} : MatSource{mats, nullptr, nullptr};
     if (GUIDED) fill_grid_solid_angles();
 
@@ -702,7 +707,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
 #pragma unroll
             for (int burst = 0; burst < PTMI_NODE_BURST; burst++) {
                 if (phase == PH_NODE) {                                // one node of Scene::intersect_bvh_optimized (scene.h:63-106)
-                    const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+                    float4 n0, n1;
+                    if (PACKED && cur < n_top) { n0 = smem[2 * cur]; n1 = smem[2 * cur + 1]; }
+                    else { n0 = nodes[2 * cur]; n1 = nodes[2 * cur + 1]; }
                     if (STATS) cn.node_visits++;
                     const int na = __float_as_int(n0.w), nb = __float_as_int(n1.w);
                     const bool pass = box_hit(n0, n1, p.o, inv, t_min, closest_t);
@@ -799,11 +806,12 @@ static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStr
 template <bool Q_, bool S_>
 static void launch_packed_one(const BounceArgs& a, dim3 grid, hipStream_t s) {
     const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
+    const size_t lds = (size_t)a.sc.n_top * 2 * sizeof(float4);
     switch (key) {
-        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, false>), grid, dim3(kBlock), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, true>), grid, dim3(kBlock), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, false>), grid, dim3(kBlock), 0, s, a); break;
-        default: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, true>), grid, dim3(kBlock), 0, s, a); break;
+        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, false>), grid, dim3(kBlock), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, true>), grid, dim3(kBlock), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, false>), grid, dim3(kBlock), lds, s, a); break;
+        default: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, true>), grid, dim3(kBlock), lds, s, a); break;
     }
 }
 static void launch_packed(const BounceArgs& a, dim3 grid, hipStream_t s) {

@@ -207,7 +207,7 @@ void SceneState::freePacked() {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d_gnodes = d_gmats = d_mtab = nullptr; d_gprims = nullptr; d_load_index = nullptr;
     d_scene.gnodes = nullptr; d_scene.n_pos = 0; d_scene.gprims = nullptr; d_scene.gmats = nullptr; d_scene.mtab = nullptr;
-    d_scene.load_index = nullptr;
+    d_scene.load_index = nullptr; d_scene.n_top = 0; d_scene.top_depth = 0;
 }
 
 // The packed layout of csrc/device_scene.h: same tree, same visiting order, records placed so that a ray touches fewer lines.
@@ -220,14 +220,37 @@ void SceneState::buildPacked() {
     std::vector<int> pos((size_t)n, -1), subtree((size_t)n, 1), stack;
     for (int i = n; i-- > 0;)
         if (!bvh_nodes[i].isLeaf()) subtree[i] = 1 + subtree[bvh_nodes[i].left_child] + subtree[bvh_nodes[i].right_child];
-    int n_pos = 2;                                     // root at 0, position 1 pads it to a pair
+    // positions: the nodes of depth <= D first, level by level (sibling pairs adjacent: the top that ptmi_bounce_phased keeps in
+    // LDS is simply "position < n_top"), then every remaining pair in pre-order of its parent
+    std::vector<int> depth((size_t)n, 0);
+    for (int i = 0; i < n; i++)
+        if (!bvh_nodes[i].isLeaf()) { depth[bvh_nodes[i].left_child] = depth[i] + 1; depth[bvh_nodes[i].right_child] = depth[i] + 1; }
+    int n_pos = 2, top_depth = -1;                     // root at 0, position 1 pads it to a pair
     pos[0] = 0;
+    {
+        std::vector<int> level{0}, next_level;
+        for (int d = 0; !level.empty(); d++) {
+            int pairs = 0;
+            for (int x : level) if (!bvh_nodes[x].isLeaf()) pairs++;
+            if (n_pos + 2 * pairs > packed_top_records) break;           // the next level no longer fits the LDS top
+            next_level.clear();
+            for (int x : level) {
+                if (bvh_nodes[x].isLeaf()) continue;
+                const int l = bvh_nodes[x].left_child, r = bvh_nodes[x].right_child;
+                pos[l] = n_pos; pos[r] = n_pos + 1; n_pos += 2;
+                next_level.push_back(l); next_level.push_back(r);
+            }
+            top_depth = d + 1;
+            level.swap(next_level);
+        }
+    }
+    const int n_top = packed_top_records >= 2 ? n_pos : 0;
     stack.push_back(0);
-    while (!stack.empty()) {                           // pairs in pre-order of their parents
+    while (!stack.empty()) {                           // the rest: pairs in pre-order of their parents
         const int x = stack.back(); stack.pop_back();
         if (bvh_nodes[x].isLeaf()) continue;
         const int l = bvh_nodes[x].left_child, r = bvh_nodes[x].right_child;
-        pos[l] = n_pos; pos[r] = n_pos + 1; n_pos += 2;
+        if (pos[l] < 0) { pos[l] = n_pos; pos[r] = n_pos + 1; n_pos += 2; }
         stack.push_back(r); stack.push_back(l);
     }
     auto position_of = [&](int pre) { return pre >= n ? n_pos : pos[pre]; };
@@ -277,7 +300,7 @@ void SceneState::buildPacked() {
     d_load_index = (int*)upload_vec(load_index.data(), load_index.size() * sizeof(int), "d_load_index");
     if (!num_quads) d_gprims = (float*)upload_vec(gp.data(), gp.size() * sizeof(float), "d_gprims");
     d_scene.gnodes = d_gnodes; d_scene.n_pos = n_pos; d_scene.gprims = d_gprims; d_scene.gmats = d_gmats; d_scene.mtab = d_mtab;
-    d_scene.load_index = d_load_index;
+    d_scene.load_index = d_load_index; d_scene.n_top = n_top; d_scene.top_depth = top_depth;
 }
 
 void SceneState::setRadiosity(const float* rgb) {

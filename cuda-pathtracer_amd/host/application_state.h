@@ -65,6 +65,8 @@ struct SceneState {
     float* d_gprims = nullptr;
     int* d_load_index = nullptr;
     int packed_min_nodes = 8192;
+    int packed_top_records = 512;                    // record positions of the packed layout kept in LDS (32 B each: 16 KB,
+                                                     // 7 waves per SIMD stay resident); < 2: none
     DeviceScene d_scene;
     // guided sampling: per-primitive PrecomputedCDF records (render_config.h:24-31), load order
     std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords: host copy, fetched on demand (precomputedCdfsHost)

@@ -27,7 +27,7 @@ EXPORTS = [
     "ptmi_host_scene_get_prims", "ptmi_host_scene_get_bvh", "ptmi_host_camera_frame", "ptmi_host_local_row_map",
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
-    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_render_frames", "ptmi_select_frame",
+    "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
 ]
 
 
@@ -140,6 +140,7 @@ def lib():
         L.ptmi_dist_barrier.argtypes = [vp]
         L.ptmi_dist_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
         L.ptmi_debug_set_packed_min_nodes.argtypes = [vp, C.c_int, ip]
+        L.ptmi_debug_set_packed_top.argtypes = [vp, C.c_int, ip, ip]
         L.ptmi_debug_place_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         _lib = L
     return _lib
@@ -484,6 +485,12 @@ class Renderer:
         n = C.c_int()
         self._ck(self.L.ptmi_debug_set_packed_min_nodes(self.h, int(min_nodes), C.byref(n)))
         return n.value
+
+    def set_packed_top(self, top_records=512):
+        """Record positions of the packed tree kept in LDS; returns (n_top, top_depth) built for the loaded scene."""
+        a = C.c_int(); b = C.c_int()
+        self._ck(self.L.ptmi_debug_set_packed_top(self.h, int(top_records), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_rcp_check(self, first_bits, count):
         bad = C.c_uint64(); first = C.c_uint32()

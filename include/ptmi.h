@@ -302,6 +302,10 @@ int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int
  * 8192), a tree no deeper than 62 and no leaf of more than 7 primitives.  Applies to the loaded scene at once and to later
  * loads; n_positions (may be NULL) receives the number of record positions built (0 = none).  Results do not depend on it. */
 int ptmi_debug_set_packed_min_nodes(ptmi_ctx*, int min_nodes, int* n_positions);
+/* How much of the packed tree every workgroup keeps in LDS: the nodes of depth <= D, D the largest depth whose levels fit
+ * top_records 32-byte records (default 512 = 16 KB; 0 = none; at most 2048).  Applies to the loaded scene at once and to
+ * later loads; n_top / top_depth (may be NULL) receive what was built.  Results do not depend on it. */
+int ptmi_debug_set_packed_top(ptmi_ctx*, int top_records, int* n_top, int* top_depth);
 /* Scene::intersect (scene.h:39-110) for n rays given as-is (no normalisation). out_*: n each; p/nrm 3n. */
 int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm);

@@ -212,13 +212,22 @@ def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
                 assert_same_image(rgb, rad, orgb, orad, f"{name} packed stats {stats} seg {seg}")
                 if stats:
                     assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        for top in (0, 6, 64, 2048):                                    # how much of the tree is walked from LDS must not matter
+            n_top, d_top = R.set_packed_top(top)
+            assert n_top <= max(top, 0) and (n_top == 0) == (top < 4)
+            assert R.set_traversal(-1) == R.PACKED
+            R.update_resolution(W, H); R.set_config(collect_stats=True); st = R.render_frame()
+            assert_same_image(*R.read_image(), orgb, orad, f"{name} packed, LDS top {top}")
+            assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+        R.set_config(collect_stats=False)
         assert R.set_traversal(R.PHASED) == R.PHASED
         R.update_resolution(W, H); R.render_frame()
         assert_same_image(*R.read_image(), orgb, orad, "phased")
         assert R.set_packed_min_nodes(1 << 30) == 0 and R.set_traversal(-1) == R.PHASED      # no packed layout: the pre-order walk
         assert R.set_traversal(R.PACKED) == R.PHASED
     finally:
-        R.set_traversal(-1); R.set_packed_min_nodes(8192); R.set_config(sampling_mode=0, segments_per_launch=0, collect_stats=False)
+        R.set_traversal(-1); R.set_packed_min_nodes(8192); R.set_packed_top(512)
+        R.set_config(sampling_mode=0, segments_per_launch=0, collect_stats=False)
 
 
 def test_deep_tree_uses_the_stack_walk_and_the_references_drop_rule(R):

@@ -17,7 +17,7 @@ res = {}
 for rd in range(rounds):
     for v in variants:
         mode, rec, blk, seg = (int(x) for x in v.split(":"))
-        top = 0
+        top = r.set_packed_top(rec)
         eff = r.set_traversal(mode)
         r.set_config(spp=spp, max_depth=8, segments_per_launch=seg, collect_stats=False)
         r.update_resolution(2048, 2048, n_ranks=8, rank=3, row_block=8)
