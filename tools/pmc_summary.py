@@ -31,7 +31,7 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
         k = row["Kernel_Name"]
         if not k.startswith("ptmi::") and "ptmi_" not in k:
             continue
-        k = k.split("(")[0].replace("void ", "").replace("ptmi::", "").split("<")[0]
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ptmi::", "").split("<")[0]
         a = agg[k][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1
 out = {"config": config, "frames": frames, **ptmi_buildinfo.stamps(),
