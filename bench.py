@@ -12,9 +12,11 @@ Workloads (BASELINE.json `configs`):
   c3      configs[2]  cbox_quads.obj 1920x1080, 1024 spp, max 5 bounces
   c5tile  configs[4]  ONE GPU's share (rank 3 of 8, interleaved 8-row blocks) of the 1,048,576-triangle 2048x2048 frame,
                       at 64 of its 2048 spp (the rate does not depend on spp): the HBM-relevant workload of this path
+  c5frame configs[4]  the whole 2048x2048 frame of that scene on ONE GPU at 64 spp: what the same kernel does when the GPU
+                      is full (an eighth of the frame is 0.52 M pixels = 8192 waves, about one per wave slot)
   c4      configs[3]  cbox.obj 4096x4096, 512 spp, max 5 bounces, rows tiled over the N GPUs (strong scaling)
   c5      configs[4]  the whole 1 M-triangle frame tiled over the N GPUs (strong scaling)
-N = 1 default: c2 as the headline line + `extra_configs` (c3, c5tile), each with its own roofline block.
+N = 1 default: c2 as the headline line + `extra_configs` (c3, c5tile, c5frame), each with its own roofline block.
 N > 1 default: weak scaling of c2 - the same view and spp at side = round(1024*sqrt(N)), so every GPU owns ~1024^2
 pixels; rows are dealt to ranks in interleaved row blocks (no data-path collective) and ONE RCCL gather at frame end
 (ptmi_gather_frame: ncclSend/ncclRecv behind the C ABI, exact tile sizes, 8-bit image) inside the timed region.
@@ -50,7 +52,7 @@ PROFILE_ROUND = "r02"
 # per wave, ~50 VALU instructions between fetches - 2.20e11 /s from a 20 MB table, 1.84e11 /s from a 120 MB one, the same at 3 and
 # at 8 waves per SIMD: the ceiling the large-scene walk runs against (its records: 20 MB of nodes, 36 MB of triangles, 16 MB of
 # material records)
-GATHER_PEAK_RECORDS_PER_S = 2.0e11
+GATHER_PEAK_RECORDS_PER_S = 2.19e11
 
 CONFIGS = {
     "c2": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce",
@@ -59,6 +61,8 @@ CONFIGS = {
                served_from="lds", what="BASELINE configs[2]"),
     "c5tile": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_phased",
                    served_from="l2/mall/hbm", what="BASELINE configs[4], one GPU's share (rank 3 of 8) at 64 of 2048 spp"),
+    "c5frame": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
+                    served_from="l2/mall/hbm", what="BASELINE configs[4], the WHOLE frame on one GPU at 64 of 2048 spp: the same kernel with a full GPU"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
     "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
@@ -208,7 +212,9 @@ def roofline_block(name, cfg, m, exact_workload):
         fetches = m["record_fetches_per_step"] / step_s
         out["gather"] = {"record_fetches_per_s": round(fetches, 1), "peak_measured": GATHER_PEAK_RECORDS_PER_S,
                          "frac": round(fetches / GATHER_PEAK_RECORDS_PER_S, 4),
-                         "what": "node visits + primitive tests + material fetches per second vs tools/gather_rate.hip (profiles/r02_gather_rate.txt)"}
+                         "lds_served_node_visits": m["top_node_visit_share"],
+                         "what": "node visits not served from the LDS top + primitive tests + material fetches per second vs tools/gather_rate.hip "
+                                 "(profiles/r02_gather_rate.txt: uniform random 32-byte records of a 20 MB table; the walk's upper levels are hotter than that)"}
     out["note"] = ("achieved = HBM bytes per step / step time, frac <= 1 by construction; algorithmic_* follow SURVEY 8(d) and count "
                    "node/triangle/material reads, which are served from " + cfg["served_from"])
     return out
@@ -235,7 +241,8 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     return dict(elapsed=elapsed, steps=steps, kernel_ms=kernel_ms, launches=launches, visits=visits, frame_dev_s=frame_dev_s,
                 bytes_per_sample=bytes_per_sample, local_samples_per_step=float(n_local_px) * cfg["spp"],
                 streams=r.config.streams or (2 if n_local_px >= (1 << 18) else 1),
-                record_fetches_per_step=float(st_counts.node_visits + st_counts.prim_tests + st_counts.hits),
+                record_fetches_per_step=float(st_counts.node_visits - st_counts.top_node_visits + st_counts.prim_tests + st_counts.hits),
+                top_node_visit_share=round(st_counts.top_node_visits / max(st_counts.node_visits, 1), 4),
                 counters=dict(rays_per_sample=round(st_counts.rays / st_counts.samples, 3),
                               nodes_per_ray=round(st_counts.node_visits / st_counts.rays, 2),
                               tests_per_ray=round(st_counts.prim_tests / st_counts.rays, 2)))
@@ -247,7 +254,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--no-extra", action="store_true", help="N = 1, config c2: skip the extra_configs (c3, c5tile)")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1, config c2: skip the extra_configs (c3, c5tile, c5frame)")
     ap.add_argument("--spp", type=int, default=0, help=argparse.SUPPRESS)          # for quick experiments only
     ap.add_argument("--side", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
@@ -418,9 +425,10 @@ def main():
     # N = 1, headline configuration: the other single-GPU workloads of BASELINE.json, driver-timed in the same run
     if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
         extras = []
-        for xname, xsteps in (("c3", 3), ("c5tile", 6)):
+        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5frame", 2)):
             xcfg = dict(CONFIGS[xname])
-            load_scene(r, xcfg["scene"])
+            if xname != "c5frame":                    # c5frame reuses the scene c5tile just loaded
+                load_scene(r, xcfg["scene"])
             allocate(xcfg)
             xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps

@@ -416,7 +416,7 @@ int ptmi_render_frame(ptmi_ctx* c, ptmi_stats* stats) {
         if (stats) {
             stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
             stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
-            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits;
+            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits; stats->top_node_visits = fs.top_node_visits;
         }
     });
 }
@@ -429,7 +429,7 @@ int ptmi_render_frames(ptmi_ctx* c, int n_frames, ptmi_stats* stats) {
         if (stats) {
             stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
             stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
-            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits;
+            stats->prim_tests = fs.prim_tests; stats->hits = fs.hits; stats->top_node_visits = fs.top_node_visits;
         }
     });
 }

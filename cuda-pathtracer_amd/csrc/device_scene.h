@@ -112,7 +112,7 @@ struct FrameParams {
     int n_local = 0;
 };
 
-struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits; };
+struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits, top_node_visits; };
 
 constexpr int kBlock = 256;
 constexpr int kXorwowJumpWords = 32 * 160 * 5;   // 32 matrices T^(2^67 * 2^k), 160 rows of 5 words

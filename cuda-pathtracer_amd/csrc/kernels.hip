@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_frame_begin(TileMap tm, PathState
     st.F[slot] = make_uint2(rng.v4, rng.d);
 }
 
-struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits; };
+struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits, top_visits; };
 
 // Slab test of scene.h:66-81 against [t_min, closest_t]; returns false when the reference would `continue`.
 // `t0 > tmin_box ? t0 : tmin_box` is written fmaxf(t0, tmin_box): identical for every input because tmin_box /
@@ -600,13 +600,14 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
         if (alive) a.queue_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
     }
     if (STATS) {
-        unsigned long long r = cn.rays, nv = cn.node_visits, pt = cn.prim_tests, h = cn.hits;
+        unsigned long long r = cn.rays, nv = cn.node_visits, pt = cn.prim_tests, h = cn.hits, tv = cn.top_visits;
         for (int off = 32; off > 0; off >>= 1) {
-            r += __shfl_down(r, off); nv += __shfl_down(nv, off); pt += __shfl_down(pt, off); h += __shfl_down(h, off);
+            r += __shfl_down(r, off); nv += __shfl_down(nv, off); pt += __shfl_down(pt, off); h += __shfl_down(h, off); tv += __shfl_down(tv, off);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&a.stats->rays, r); atomicAdd(&a.stats->node_visits, nv);
             atomicAdd(&a.stats->prim_tests, pt); atomicAdd(&a.stats->hits, h);
+            if (tv) atomicAdd(&a.stats->top_node_visits, tv);
         }
     }
 }
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SW
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
-    LaneCounters cn = {0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0};
 
     for (int seg = 0; seg < a.segments; seg++) {
         if (!__any(alive)) break;
@@ -658,6 +659,15 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SW
 // walking the tree, instead of idling until the longest ray of the wave is done (segment-synchronous per-lane walk on
 // the 1M-triangle scene: 13.8 % VALU lane utilisation).  Per lane the sequence of node visits, primitive tests and RNG
 // draws is exactly the reference's; only the interleaving between lanes changes.
+#ifdef PTMI_TRACE_WAVES
+// experiment-only build (tools/wave_trace.py, never the shipped library): where a wave's clocks go.  [0] walk clocks
+// [1] shade clocks [2] walk decisions [3] shade decisions [4] lanes advanced by walk decisions [5] lanes shaded [6] wave clocks
+// [7] waves [8] longest wave [9] clocks outside the loop [10] living lanes summed over decisions [11] node decisions [12] node clocks
+__device__ unsigned long long g_trace[16];
+#define PTMI_TR(...) __VA_ARGS__
+#else
+#define PTMI_TR(...)
+#endif
 #ifndef PTMI_NODE_BURST
 #define PTMI_NODE_BURST 3
 #endif
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
-    LaneCounters cn = {0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0};
 
     enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
     const int n_nodes = PACKED ? a.sc.n_pos : a.sc.n_nodes, prim_stride = a.sc.prim_stride;     // cursor >= n_nodes: walk finished
@@ -696,11 +706,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     f3 inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));
     if (STATS && alive) cn.rays++;
 
+    PTMI_TR(const long long tr_t0 = clock64(); long long tr_walk = 0, tr_shade = 0, tr_node = 0; unsigned tr_nw = 0, tr_ns = 0, tr_lw = 0, tr_ls = 0, tr_alive = 0, tr_nn = 0;)
     while (true) {
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_prim = __popcll(__ballot(phase == PH_PRIM));
         const int c_shade = __popcll(__ballot(phase == PH_SHADE));
         if (c_node + c_prim + c_shade == 0) break;
+        PTMI_TR(const long long tr_a = clock64(); tr_alive += c_node + c_prim + c_shade;
+                const int tr_kind = c_node >= c_prim && c_node >= c_shade ? 0 : c_prim >= c_shade ? 1 : 2;
+                if (tr_kind == 0) { tr_nw++; tr_nn++; tr_lw += c_node; } else if (tr_kind == 1) { tr_nw++; tr_lw += c_prim; } else { tr_ns++; tr_ls += c_shade; })
         if (c_node >= c_prim && c_node >= c_shade) {
             // a short burst of node steps per scheduling decision: in large scenes a ray visits ~10 nodes between two
             // leaves, and the three ballots + branches of a decision cost about as much as a node test
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
             for (int burst = 0; burst < PTMI_NODE_BURST; burst++) {
                 if (phase == PH_NODE) {                                // one node of Scene::intersect_bvh_optimized (scene.h:63-106)
                     float4 n0, n1;
-                    if (PACKED && cur < n_top) { n0 = smem[2 * cur]; n1 = smem[2 * cur + 1]; }
+                    if (PACKED && cur < n_top) { n0 = smem[2 * cur]; n1 = smem[2 * cur + 1]; if (STATS) cn.top_visits++; }
                     else { n0 = nodes[2 * cur]; n1 = nodes[2 * cur + 1]; }
                     if (STATS) cn.node_visits++;
                     const int na = __float_as_int(n0.w), nb = __float_as_int(n1.w);
@@ -751,11 +765,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
                 }
             }
         }
+        PTMI_TR(const long long tr_d = clock64() - tr_a; if (tr_kind == 2) tr_shade += tr_d; else tr_walk += tr_d; if (tr_kind == 0) tr_node += tr_d;)
     }
+    PTMI_TR(const long long tr_loop = clock64() - tr_t0;)
 
     if (active) store_path(a.st, slot, p);
     finish_launch<STATS>(a, alive, slot, cn);
+#ifdef PTMI_TRACE_WAVES
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long tot = (unsigned long long)(clock64() - tr_t0);
+        const unsigned long long v[13] = {(unsigned long long)tr_walk, (unsigned long long)tr_shade, tr_nw, tr_ns, tr_lw, tr_ls, tot, 1ull, 0ull,
+                                          tot - (unsigned long long)tr_loop, tr_alive, tr_nn, (unsigned long long)tr_node};
+        for (int i = 0; i < 13; i++) if (i != 8) atomicAdd(&g_trace[i], v[i]);
+        atomicMax(&g_trace[8], tot);
+    }
+#endif
 }
+
+#ifdef PTMI_TRACE_WAVES
+extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and clears the counters
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
     size_t b = 0;
@@ -914,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_render_radiosity(DeviceScene sc, 
         rng = Rng{e.x, e.y, e.z, e.w, f.x, f.y};                                      // curandState local_rng = rand_state[pixel_index]
     }
     f3 color = mk3(0.0f, 0.0f, 0.0f);
-    LaneCounters cn = {0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0};
     for (int s = 0; s < fp.spp; s++) {
         f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         if (live) camera_ray(fp, tm, x, y, rng, o, d);
@@ -965,7 +998,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_k(DeviceScene sc,
     const bool live = i < n;
     const int j = live ? i : 0;
     const f3 ro = mk3(o[3 * j], o[3 * j + 1], o[3 * j + 2]), rd = mk3(d[3 * j], d[3 * j + 1], d[3 * j + 2]);
-    LaneCounters cn = {0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0};
     float t = 0.0f; int k = -1;
     const bool h = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, ro, rd, t_min, t_max, t, k, cn);
     if (!live) return;

@@ -810,6 +810,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
             StatCounters c;
             PTMI_HIP(hipMemcpy(&c, r.d_stats, sizeof c, hipMemcpyDeviceToHost));
             stats->rays = c.rays; stats->node_visits = c.node_visits; stats->prim_tests = c.prim_tests; stats->hits = c.hits;
+            stats->top_node_visits = c.top_node_visits;
         }
     }
 }

@@ -207,7 +207,7 @@ void debugPlaceTiles(int width, int height, int n_ranks, int row_block, const un
 
 struct FrameStats {
     double seconds = 0, bounce_kernel_ms = 0;
-    uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0;
+    uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0, top_node_visits = 0;
 };
 
 struct ApplicationState {

@@ -60,7 +60,7 @@ class RadiosityStats(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("path_visits", C.c_uint64),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("hits", C.c_uint64)]
+                ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("top_node_visits", C.c_uint64)]
 
 
 class PtmiError(RuntimeError):

@@ -107,6 +107,7 @@ typedef struct {
     uint64_t path_visits;      /* sum over launches of queued pixels: each reads + writes its 88-byte state once */
     uint64_t samples;          /* local pixels * spp */
     uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */
+    uint64_t top_node_visits;  /* of node_visits, those served from the LDS-staged top of the packed layout (large scenes; else 0) */
 } ptmi_stats;
 
 /* RadiosityState + the filter switches of AppConfig (application_state.h:207-209, 290-291), defaults in comments */

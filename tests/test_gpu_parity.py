@@ -219,6 +219,9 @@ def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
             R.update_resolution(W, H); R.set_config(collect_stats=True); st = R.render_frame()
             assert_same_image(*R.read_image(), orgb, orad, f"{name} packed, LDS top {top}")
             assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+            # every ray visits the root (position 0 < n_top); nothing is served from LDS without a top
+            assert (st.top_node_visits == 0) if n_top == 0 else (st.rays <= st.top_node_visits <= st.node_visits)
+            if n_top >= R.scene_info()["n_bvh_nodes"] + 1: assert st.top_node_visits == st.node_visits
         R.set_config(collect_stats=False)
         assert R.set_traversal(R.PHASED) == R.PHASED
         R.update_resolution(W, H); R.render_frame()

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
 import numpy as np, ptmi, ptmi_scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["3:0:0:0", "4:0:0:0"]     # mode:unused:unused:segments
+variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["3:0:0:0", "4:0:0:0"]     # mode:lds_top_records:streams:segments
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 base = ptmi.HostScene.load(os.path.join(ROOT, "tests/golden/scenes/cbox_quads.obj")).prims()
 sc = ptmi_scenes.tessellated_cornell(base, 256, 128)
@@ -17,9 +17,9 @@ res = {}
 for rd in range(rounds):
     for v in variants:
         mode, rec, blk, seg = (int(x) for x in v.split(":"))
-        top = r.set_packed_top(rec)
+        top = r.set_packed_top(rec if rec else 512)
         eff = r.set_traversal(mode)
-        r.set_config(spp=spp, max_depth=8, segments_per_launch=seg, collect_stats=False)
+        r.set_config(spp=spp, max_depth=8, segments_per_launch=seg, collect_stats=False, streams=blk)
         r.update_resolution(2048, 2048, n_ranks=8, rank=3, row_block=8)
         t0 = time.perf_counter(); st = r.render_frame(); dt = time.perf_counter() - t0
         if rd == 0:
