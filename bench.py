@@ -31,6 +31,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver stack
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,7 @@
 // c_api.cpp — the C ABI of libptmi.so (include/ptmi.h) over the host-side state objects.
 #include "../../include/ptmi.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -74,6 +75,9 @@ void ptmi_default_config(ptmi_config* c) {
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
 int ptmi_ctx_create(int device_id, ptmi_ctx** out) {
+    // multi-process GPU work (the RCCL gather) needs dmabuf IPC on this driver stack; only takes effect if the process has
+    // not initialised HIP yet and does not say otherwise
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     return guarded([&] { need(out != nullptr, "out is NULL"); *out = nullptr; *out = new ptmi_ctx(device_id); });
 }
 void ptmi_ctx_destroy(ptmi_ctx* c) { delete c; }
