@@ -836,26 +836,30 @@ static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStr
         default: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true, false, true>), grid, dim3(kBlock), lds, s, a); break;
     }
 }
-template <bool Q_, bool S_>
-static void launch_packed_one(const BounceArgs& a, dim3 grid, hipStream_t s) {
+// f(kernel, dynamic LDS bytes) for the instantiation of the packed walk that `a` selects
+template <bool Q_, bool S_, typename F>
+static void with_packed_kernel_qs(const BounceArgs& a, F&& f) {
     const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
     const size_t lds = (size_t)a.sc.n_top * 2 * sizeof(float4);
     switch (key) {
-        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, false>), grid, dim3(kBlock), lds, s, a); break;
-        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, false, true, true>), grid, dim3(kBlock), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, false>), grid, dim3(kBlock), lds, s, a); break;
-        default: hipLaunchKernelGGL((ptmi_bounce_phased<false, Q_, S_, true, true, true>), grid, dim3(kBlock), lds, s, a); break;
+        case 0: f(ptmi_bounce_phased<false, Q_, S_, false, true, false>, lds); break;
+        case 1: f(ptmi_bounce_phased<false, Q_, S_, false, true, true>, lds); break;
+        case 2: f(ptmi_bounce_phased<false, Q_, S_, true, true, false>, lds); break;
+        default: f(ptmi_bounce_phased<false, Q_, S_, true, true, true>, lds); break;
+    }
+}
+template <typename F>
+static void with_packed_kernel(const BounceArgs& a, F&& f) {
+    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
+    switch (key) {
+        case 0: with_packed_kernel_qs<false, false>(a, f); break;
+        case 1: with_packed_kernel_qs<false, true>(a, f); break;
+        case 2: with_packed_kernel_qs<true, false>(a, f); break;
+        default: with_packed_kernel_qs<true, true>(a, f); break;
     }
 }
 static void launch_packed(const BounceArgs& a, dim3 grid, hipStream_t s) {
-
-    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    switch (key) {
-        case 0: launch_packed_one<false, false>(a, grid, s); break;
-        case 1: launch_packed_one<false, true>(a, grid, s); break;
-        case 2: launch_packed_one<true, false>(a, grid, s); break;
-        default: launch_packed_one<true, true>(a, grid, s); break;
-    }
+    with_packed_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 template <bool G_>
 static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -880,6 +884,17 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
     else if (sc.traversal == TRAVERSAL_PHASED) { if (sc.lds_resident) launch_phased<true>(a, grid, lds, s); else launch_phased<false>(a, grid, lds, s); }
     else if (sc.traversal == TRAVERSAL_PACKED) launch_packed(a, grid, s);
     else launch_bounce_mode<TRAVERSAL_STACK>(a, grid, lds, s);
+}
+
+// waves of the packed walk that the device holds at once (0: the scene is not walked by it)
+int packed_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
+    if (sc.traversal != TRAVERSAL_PACKED) return 0;
+    BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr};
+    int blocks = 0;
+    with_packed_kernel(a, [&](auto kernel, size_t lds) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;
+    });
+    return blocks * (kBlock / 64) * n_cus;
 }
 
 void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* d_jump, uint64_t seed_base, hipStream_t s) {

@@ -612,6 +612,7 @@ ApplicationState::ApplicationState(int device) : device_id(device) {
     PTMI_HIP(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         throw HipError(hipErrorInvalidDevice, std::string("libptmi is built for gfx950 only; device is ") + prop.gcnArchName);
+    n_cus = prop.multiProcessorCount;
     PTMI_HIP(hipStreamCreateWithFlags(&render.stream, hipStreamNonBlocking));
     for (RenderState::Chunk& c : render.chunk) PTMI_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     h_jump = buildXorwowJumpMatrices();
@@ -682,7 +683,16 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     r.batch_frames = n_frames; r.batch_spp = g.config.spp;
 
     const int n_local = (int)r.n_local;
-    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
+    // segments per launch.  32 everywhere, except where the packed walk's waves all fit the device at once (an eighth of a
+    // 2048^2 frame per GPU): there the frame is as long as the chain of its heaviest pixels, every launch boundary makes it wait
+    // for the slowest wave once more, and the whole frame as ONE launch per chunk is 20 % faster (1 M-triangle scene, 47 vs
+    // 59 ms); with more waves than slots it is slower (the waves of the second round start a whole chain late) - DESIGN.md 5
+    int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
+    if (g.config.segments_per_launch <= 0 && g.config.current_integrator != IntegratorType::Radiosity) {
+        const long long waves = ((long long)r.n_local + 63) / 64;
+        const long long slots = packed_resident_waves(g.scene.d_scene, fp, g.config.collect_stats, g.n_cus);
+        if (slots > 0 && waves * 100 <= slots * 120) segments = std::numeric_limits<int>::max();
+    }
     hipStream_t s = r.stream;
     // whatever way this function is left, nothing of this frame is still in flight (an exception thrown between two
     // launches must not let the next frame start on top of the chunk streams' queued work)

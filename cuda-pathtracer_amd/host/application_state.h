@@ -212,6 +212,7 @@ struct FrameStats {
 
 struct ApplicationState {
     int device_id = 0;
+    int n_cus = 0;                                   // compute units of the device
     RenderState render;
     SceneState scene;
     RadiosityState radiosity;

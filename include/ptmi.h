@@ -69,7 +69,8 @@ typedef struct {
     uint64_t seed_base;       /* 2023 */
     /* scheduling knob, results are independent of it: ray segments each path
      * advances per kernel launch before state returns to HBM and the active
-     * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default */
+     * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default: 32, or the whole frame in one
+     * launch per chunk when a large scene's waves all but fit the device at once */
     int      segments_per_launch;
     int      collect_stats;   /* 1: also count rays / node visits / primitive tests (slower build of the kernel) */
     /* scheduling knob, results are independent of it: which 64 pixels share a wave.  0 = default (64x1 row strips),

@@ -12,7 +12,7 @@ import numpy as np
 for n_ranks in ([int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (16, 8, 4, 2, 1)):
     ref = None
     for mode in modes:
-        seg = 0
+        seg = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # segments per launch (0 = the library's default)
         top = None
         if mode >= 100: top = mode - 100; r.set_packed_top(top); mode = 4          # 100 + n: packed layout with an n-record LDS top
         r.set_traversal(mode)
