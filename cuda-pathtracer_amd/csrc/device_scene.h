@@ -127,7 +127,7 @@ void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParam
 // queue_in == nullptr means "all local pixels" (identity queue); n_in is then the pixel count.  count_in (device
 // pointer, may be nullptr) holds the exact length of queue_in when the host only knows the upper bound n_in: the
 // host can then enqueue launches ahead of the counts coming back.
-int packed_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus);
+int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus);
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */, hipStream_t s);

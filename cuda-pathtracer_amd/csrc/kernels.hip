@@ -801,74 +801,58 @@ size_t bounce_lds_bytes(const DeviceScene& sc) {
 // guided = sampling_mode != SAMPLING_BSDF and CDF records present; otherwise the lean BSDF instantiation runs
 static bool is_guided(const BounceArgs& a) { return a.fp.sampling_mode != 0 && a.sc.cdfs != nullptr; }
 
-template <int MODE, bool G_, bool Q_, bool S_>
-static void launch_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
-    switch (key) {
-        case 0: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false, false>), grid, dim3(kBlock), lds, s, a); break;
-        case 1: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, false, true>), grid, dim3(kBlock), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true, false>), grid, dim3(kBlock), lds, s, a); break;
-        default: hipLaunchKernelGGL((ptmi_bounce<MODE, G_, Q_, S_, true, true>), grid, dim3(kBlock), lds, s, a); break;
+// ---- kernel selection: f(kernel, dynamic LDS bytes) is called for the ONE instantiation that `a` selects -----------------
+template <int MODE, bool G_, bool Q_, bool S_, typename F>
+static void with_bounce_gb(const BounceArgs& a, size_t lds, F&& f) {
+    switch ((is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
+        case 0: f(ptmi_bounce<MODE, G_, Q_, S_, false, false>, lds); break;
+        case 1: f(ptmi_bounce<MODE, G_, Q_, S_, false, true>, lds); break;
+        case 2: f(ptmi_bounce<MODE, G_, Q_, S_, true, false>, lds); break;
+        default: f(ptmi_bounce<MODE, G_, Q_, S_, true, true>, lds); break;
     }
 }
-template <int MODE, bool G_>
-static void launch_qs(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    switch (key) {
-        case 0: launch_one<MODE, G_, false, false>(a, grid, lds, s); break;
-        case 1: launch_one<MODE, G_, false, true>(a, grid, lds, s); break;
-        case 2: launch_one<MODE, G_, true, false>(a, grid, lds, s); break;
-        default: launch_one<MODE, G_, true, true>(a, grid, lds, s); break;
+template <bool G_, bool Q_, bool S_, bool PACKED, typename F>
+static void with_phased_gb(const BounceArgs& a, size_t lds, F&& f) {
+    switch ((is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
+        case 0: f(ptmi_bounce_phased<G_, Q_, S_, false, PACKED, false>, lds); break;
+        case 1: f(ptmi_bounce_phased<G_, Q_, S_, false, PACKED, true>, lds); break;
+        case 2: f(ptmi_bounce_phased<G_, Q_, S_, true, PACKED, false>, lds); break;
+        default: f(ptmi_bounce_phased<G_, Q_, S_, true, PACKED, true>, lds); break;
     }
 }
-template <int MODE>
-static void launch_bounce_mode(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    if (MODE == TRAVERSAL_SWEEP || a.sc.lds_resident) launch_qs<MODE, true>(a, grid, lds, s);
-    else if (MODE != TRAVERSAL_SWEEP) launch_qs<MODE == TRAVERSAL_SWEEP ? TRAVERSAL_STACK : MODE, false>(a, grid, lds, s);
-}
-template <bool G_, bool Q_, bool S_>
-static void launch_phased_one(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
-    switch (key) {
-        case 0: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false, false, false>), grid, dim3(kBlock), lds, s, a); break;
-        case 1: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, false, false, true>), grid, dim3(kBlock), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true, false, false>), grid, dim3(kBlock), lds, s, a); break;
-        default: hipLaunchKernelGGL((ptmi_bounce_phased<G_, Q_, S_, true, false, true>), grid, dim3(kBlock), lds, s, a); break;
+// KIND: 0..2 = ptmi_bounce<TraversalMode>, 3 = ptmi_bounce_phased over the scene arrays, 4 = over the packed layout
+template <int KIND, bool G_, typename F>
+static void with_bounce_qs(const BounceArgs& a, size_t lds, F&& f) {
+#define PTMI_QS(Q_, S_)                                                                               \
+    do {                                                                                              \
+        if constexpr (KIND == 4) with_phased_gb<false, Q_, S_, true>(a, lds, f);                      \
+        else if constexpr (KIND == 3) with_phased_gb<G_, Q_, S_, false>(a, lds, f);                   \
+        else with_bounce_gb<KIND, G_, Q_, S_>(a, lds, f);                                             \
+    } while (0)
+    switch ((a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0)) {
+        case 0: PTMI_QS(false, false); break;
+        case 1: PTMI_QS(false, true); break;
+        case 2: PTMI_QS(true, false); break;
+        default: PTMI_QS(true, true); break;
     }
-}
-// f(kernel, dynamic LDS bytes) for the instantiation of the packed walk that `a` selects
-template <bool Q_, bool S_, typename F>
-static void with_packed_kernel_qs(const BounceArgs& a, F&& f) {
-    const int key = (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0);
-    const size_t lds = (size_t)a.sc.n_top * 2 * sizeof(float4);
-    switch (key) {
-        case 0: f(ptmi_bounce_phased<false, Q_, S_, false, true, false>, lds); break;
-        case 1: f(ptmi_bounce_phased<false, Q_, S_, false, true, true>, lds); break;
-        case 2: f(ptmi_bounce_phased<false, Q_, S_, true, true, false>, lds); break;
-        default: f(ptmi_bounce_phased<false, Q_, S_, true, true, true>, lds); break;
-    }
+#undef PTMI_QS
 }
 template <typename F>
-static void with_packed_kernel(const BounceArgs& a, F&& f) {
-    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    switch (key) {
-        case 0: with_packed_kernel_qs<false, false>(a, f); break;
-        case 1: with_packed_kernel_qs<false, true>(a, f); break;
-        case 2: with_packed_kernel_qs<true, false>(a, f); break;
-        default: with_packed_kernel_qs<true, true>(a, f); break;
-    }
-}
-static void launch_packed(const BounceArgs& a, dim3 grid, hipStream_t s) {
-    with_packed_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
-}
-template <bool G_>
-static void launch_phased(const BounceArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    const int key = (a.sc.has_quads ? 2 : 0) | (a.stats ? 1 : 0);
-    switch (key) {
-        case 0: launch_phased_one<G_, false, false>(a, grid, lds, s); break;
-        case 1: launch_phased_one<G_, false, true>(a, grid, lds, s); break;
-        case 2: launch_phased_one<G_, true, false>(a, grid, lds, s); break;
-        default: launch_phased_one<G_, true, true>(a, grid, lds, s); break;
+static void with_bounce_kernel(const BounceArgs& a, F&& f) {
+    const DeviceScene& sc = a.sc;
+    const size_t lds = bounce_lds_bytes(sc);
+    switch (sc.traversal) {
+        case TRAVERSAL_SWEEP: with_bounce_qs<TRAVERSAL_SWEEP, true>(a, lds, f); break;          // the sweep reads the scene through LDS
+        case TRAVERSAL_LANE:
+            if (sc.lds_resident) with_bounce_qs<TRAVERSAL_LANE, true>(a, lds, f); else with_bounce_qs<TRAVERSAL_LANE, false>(a, lds, f);
+            break;
+        case TRAVERSAL_PHASED:
+            if (sc.lds_resident) with_bounce_qs<3, true>(a, lds, f); else with_bounce_qs<3, false>(a, lds, f);
+            break;
+        case TRAVERSAL_PACKED: with_bounce_qs<4, false>(a, (size_t)sc.n_top * 2 * sizeof(float4), f); break;
+        default:
+            if (sc.lds_resident) with_bounce_qs<TRAVERSAL_STACK, true>(a, lds, f); else with_bounce_qs<TRAVERSAL_STACK, false>(a, lds, f);
+            break;
     }
 }
 
@@ -878,20 +862,14 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
     if (n_in <= 0) return;
     BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats};
     const dim3 grid((n_in + kBlock - 1) / kBlock);
-    const size_t lds = bounce_lds_bytes(sc);
-    if (sc.traversal == TRAVERSAL_SWEEP) launch_bounce_mode<TRAVERSAL_SWEEP>(a, grid, lds, s);
-    else if (sc.traversal == TRAVERSAL_LANE) launch_bounce_mode<TRAVERSAL_LANE>(a, grid, lds, s);
-    else if (sc.traversal == TRAVERSAL_PHASED) { if (sc.lds_resident) launch_phased<true>(a, grid, lds, s); else launch_phased<false>(a, grid, lds, s); }
-    else if (sc.traversal == TRAVERSAL_PACKED) launch_packed(a, grid, s);
-    else launch_bounce_mode<TRAVERSAL_STACK>(a, grid, lds, s);
+    with_bounce_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 
-// waves of the packed walk that the device holds at once (0: the scene is not walked by it)
-int packed_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
-    if (sc.traversal != TRAVERSAL_PACKED) return 0;
+// waves of the frame's bounce kernel that the device holds at once (0: unknown)
+int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
     BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr};
     int blocks = 0;
-    with_packed_kernel(a, [&](auto kernel, size_t lds) {
+    with_bounce_kernel(a, [&](auto kernel, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;
     });
     return blocks * (kBlock / 64) * n_cus;

@@ -683,16 +683,17 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     r.batch_frames = n_frames; r.batch_spp = g.config.spp;
 
     const int n_local = (int)r.n_local;
-    // segments per launch.  32 everywhere, except where the packed walk's waves all fit the device at once (an eighth of a
-    // 2048^2 frame per GPU): there the frame is as long as the chain of its heaviest pixels, every launch boundary makes it wait
-    // for the slowest wave once more, and the whole frame as ONE launch per chunk is 20 % faster (1 M-triangle scene, 47 vs
-    // 59 ms); with more waves than slots it is slower (the waves of the second round start a whole chain late) - DESIGN.md 5
-    int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
-    if (g.config.segments_per_launch <= 0 && g.config.current_integrator != IntegratorType::Radiosity) {
-        const long long waves = ((long long)r.n_local + 63) / 64;
-        const long long slots = packed_resident_waves(g.scene.d_scene, fp, g.config.collect_stats, g.n_cus);
-        if (slots > 0 && waves * 100 <= slots * 120) segments = std::numeric_limits<int>::max();
-    }
+    // segments per launch: 32 while the device has more waves to run than it holds at once; once the pixels still active fit
+    // (an eighth of a 2048^2 frame per GPU from its first launch on; the last stretch of any other frame), the frame is as
+    // long as the chain of its heaviest pixels, every launch boundary makes it wait for the slowest wave once more, and the
+    // rest of the frame goes into ONE launch per chunk (1 M-triangle scene, 1/8 of the frame: 47 instead of 59 ms; with more
+    // waves than slots one launch is slower, the second round starts a whole chain late) - DESIGN.md 5
+    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
+    // (the phased kernels only: the sweep's cost per segment does not shrink with its living lanes, so its waves want the
+    // compaction of every 32nd segment to the end - c2 -7 %, c3 -8 % with the rule applied to it)
+    const int trav = g.scene.d_scene.traversal;
+    const long long wave_slots = g.config.segments_per_launch > 0 || (trav != TRAVERSAL_PHASED && trav != TRAVERSAL_PACKED)
+                                     ? 0 : bounce_resident_waves(g.scene.d_scene, fp, g.config.collect_stats, g.n_cus);
     hipStream_t s = r.stream;
     // whatever way this function is left, nothing of this frame is still in flight (an exception thrown between two
     // launches must not let the next frame start on top of the chunk streams' queued work)
@@ -762,9 +763,12 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 PTMI_HIP(hipMemsetAsync(ch.d_count + slot_out, 0, sizeof(int), ch.stream));
                 const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
+                long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
+                for (int k = 0; k < r.n_chunks; k++) active += run[k].finished ? 0 : run[k].bound;
+                const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * 120;
                 launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
-                              segments, want_stats ? r.d_stats : nullptr, ch.stream);
+                              fits ? std::numeric_limits<int>::max() : segments, want_stats ? r.d_stats : nullptr, ch.stream);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
