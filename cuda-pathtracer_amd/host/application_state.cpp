@@ -689,6 +689,10 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // rest of the frame goes into ONE launch per chunk (1 M-triangle scene, 1/8 of the frame: 47 instead of 59 ms; with more
     // waves than slots one launch is slower, the second round starts a whole chain late) - DESIGN.md 5
     const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
+    // "the rest of the frame": bounded so that one launch stays well below a minute (a lane of the 1 M-triangle scene does
+    // ~4 000 segments per second; BASELINE's 2048 spp x 8 bounces = 16 384 segments at most = ONE 1.45 s launch per chunk.  A
+    // boundary in mid-frame is dear: with 8 192 the same frame took 1.58 s)
+    constexpr int kRestOfFrameSegments = 65536;
     // (the phased kernels only: the sweep's cost per segment does not shrink with its living lanes, so its waves want the
     // compaction of every 32nd segment to the end - c2 -7 %, c3 -8 % with the rule applied to it)
     const int trav = g.scene.d_scene.traversal;
@@ -768,7 +772,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * 120;
                 launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
-                              fits ? std::numeric_limits<int>::max() : segments, want_stats ? r.d_stats : nullptr, ch.stream);
+                              fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr, ch.stream);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
