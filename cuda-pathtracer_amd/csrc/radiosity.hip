@@ -43,8 +43,9 @@ __device__ __forceinline__ f3 bary_point(f3 a, f3 b, f3 c, float r1, float r2) {
     return u * a + v * b + w * c;
 }
 // Primitive::sampleUniform (primitive.h:150-191); the quad's area ratio comes precomputed from the host
+template <bool HAS_QUADS>
 __device__ __forceinline__ f3 sample_uniform(const Geom& g, float r1, float r2) {
-    if (g.type == 0) return bary_point(g.v0, g.v1, g.v2, r1, r2);
+    if (!HAS_QUADS || g.type == 0) return bary_point(g.v0, g.v1, g.v2, r1, r2);      // triangle-only scenes: v3 / ratio / type stay out of registers
     if (r1 < g.ratio) return bary_point(g.v0, g.v1, g.v3, r1 / g.ratio, r2);                     // (v00, v10, v01)
     return bary_point(g.v1, g.v2, g.v3, (r1 - g.ratio) / (1.0f - g.ratio), r2);                  // (v10, v11, v01)
 }
@@ -196,16 +197,20 @@ __device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __res
 }
 
 // the sample loop and F_ij of calculate_form_factors_mc_kernel (form_factors.h:259-365) for one surviving pair
+// The emitter's record is read again for every sample (it is L1-resident, and only the sample's first lines use it): its
+// 13 - 18 registers do not have to live through the visibility walk, where the kernel is short of them (7 waves per SIMD).
 template <bool HAS_QUADS, bool DEEP, bool RAD0>
-__device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, const Geom& gj, int slot_i, int slot_j, int actual_samples,
-                                         Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays) {
+__device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, const float4* __restrict__ geo, int j, int slot_i, int slot_j,
+                                         int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays) {
     float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
     int valid_samples = 0;
     for (int s = 0; s < actual_samples; ++s) {
+        asm volatile("" ::: "memory");                                          // keeps the loads below inside the loop
+        const Geom gj = load_geom(geo, j);
         float r1 = rng_uniform(rng), r2 = rng_uniform(rng);
-        const f3 p_i = sample_uniform(gi, r1, r2);
+        const f3 p_i = sample_uniform<HAS_QUADS>(gi, r1, r2);
         r1 = rng_uniform(rng); r2 = rng_uniform(rng);
-        const f3 p_j = sample_uniform(gj, r1, r2);
+        const f3 p_j = sample_uniform<HAS_QUADS>(gj, r1, r2);
         f3 sample_dir = p_j - p_i;
         const float r = length(sample_dir);
         if (r < 1e-6f) continue;
@@ -233,7 +238,8 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, 
         const float avg_cos_j = cos_j_sum / (float)valid_samples;
         const float avg_dist = dist_sum / (float)valid_samples;
         const float visibility_fraction = visibility_sum / (float)actual_samples;
-        const float F_ij = (float)((double)(visibility_fraction * (avg_cos_i * avg_cos_j * gj.area)) /
+        const float area_j = geo[6 * j + 1].w;
+        const float F_ij = (float)((double)(visibility_fraction * (avg_cos_i * avg_cos_j * area_j)) /
                                    (PTMI_PI_D * (double)avg_dist * (double)avg_dist));
         return fmaxf(0.0f, fminf(F_ij, 1.0f));
     }
@@ -256,8 +262,12 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, const Geom& gi,
     return fmaxf(0.0f, ff);
 }
 
+// 7 waves per SIMD (72 VGPRs, 23 dwords spilled) instead of the 4 the kernel asks for by itself (112 VGPRs): the any-hit walks
+// wait on L2, and more waves in flight are worth more than the spills cost - n = 8192: 4 / 5 / 6 / 7 / 8 waves 168.6 / 151.6 /
+// 139.0 / 134.8 / 133.5 ms, and 131.4 ms at 7 waves with the emitter's record re-read per sample (mc_pair); n = 2048: 7 waves
+// 14.5 ms, 8 waves 15.0 ms
 template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0>
-__global__ __launch_bounds__(kBlock) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
+__global__ __launch_bounds__(kBlock, 7) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
                                                             const uint32_t* __restrict__ jump) {
     __shared__ uint32_t M[160 * 5];
     __shared__ unsigned int counts[kGridSize];
@@ -325,11 +335,10 @@ __global__ __launch_bounds__(kBlock) void ptmi_form_factors(DeviceScene sc, Radi
             Rng rng = {0u, 0u, 0u, 0u, 0u, 0u};
             if (MC) pair_rng_init(M, jump, have, (unsigned int)(i * n + e.x), rng);
             if (have) {
-                const Geom gj = load_geom(rb.geo, e.x);
                 const int slot_j = rb.slot_of[e.x];
                 float F;
-                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0>(sc, gi, gj, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
-                else F = p2p_pair<HAS_QUADS, DEEP>(sc, gi, gj, slot_i, slot_j, rays);
+                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0>(sc, gi, rb.geo, e.x, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
+                else F = p2p_pair<HAS_QUADS, DEEP>(sc, gi, load_geom(rb.geo, e.x), slot_i, slot_j, rays);
                 row[e.x] = F;
             }
             __syncthreads();
