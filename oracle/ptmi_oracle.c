@@ -614,7 +614,10 @@ void po_camera_ray(const po_camera_frame* c, float u, float v, float o[3], float
 /* Published algorithm restated: Marsaglia xorwow + Weyl sequence; curand_init */
 /* seed scrambling; subsequence = 2^67 steps, skipped with GF(2) matrix powers;*/
 /* curand_uniform = x * 2^-32 + 2^-33 in (0,1].                                */
-/* Call sites: integrator.h:63-64, 210, 279, 384-385.  UNPINNED vs real cuRAND.*/
+/* Call sites: integrator.h:63-64, 210, 279, 384-385.  UNPINNED vs real cuRAND; */
+/* the step and the 2^67 skip-ahead are pinned against rocRAND's implementation */
+/* of the same generator (rocrand_harness.cpp, tests/test_rng_vs_rocrand.py),   */
+/* the seed scramble and the float conversion are not (rocRAND's differ).       */
 /* ------------------------------------------------------------------------ */
 typedef struct { uint32_t row[160][5]; } xmat;
 static xmat g_jump[32];          /* g_jump[k] = T^(2^67 * 2^k) */
@@ -689,6 +692,15 @@ int po_rng_selftest(int log2n, const uint32_t v_in[5]) {
     for (uint64_t i = 0; i < (1ull << log2n); i++) xorwow_step_v(direct);
     free(a); free(b);
     return memcmp(viaM, direct, sizeof direct) == 0 ? 0 : 1;
+}
+
+/* test hooks for the pin against rocRAND's implementation of the same generator (oracle/rocrand_harness.cpp): raw draws from
+ * a given state, and the skip over n subsequences of 2^67 draws as po_rng_init applies it */
+void po_xorwow_next_raw(uint32_t st[6], int n, uint32_t* out) { for (int i = 0; i < n; i++) out[i] = xorwow_next(st); }
+void po_xorwow_skip_subsequences(uint32_t v[5], uint64_t n) {
+    init_jump_tables();
+    for (int k = 0; k < 32; k++)
+        if (n & (1ull << k)) { uint32_t o[5]; xmat_apply(&g_jump[k], v, o); memcpy(v, o, sizeof o); }
 }
 
 void po_sincosf(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }

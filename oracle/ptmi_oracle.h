@@ -93,6 +93,8 @@ void po_camera_ray(const po_camera_frame*, float u, float v, float o[3], float d
 void po_rng_init(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
 float po_rng_uniform(uint32_t state[6]);
 int po_rng_selftest(int log2n, const uint32_t v_in[5]);
+void po_xorwow_next_raw(uint32_t state[6], int n, uint32_t* out);       /* n raw 32-bit draws (state: x[0..4], d) */
+void po_xorwow_skip_subsequences(uint32_t v[5], uint64_t n);            /* n < 2^32 subsequences of 2^67 draws */
 void po_sincosf(float x, float* s, float* c);
 float po_powf(float x, float y);
 float po_acosf(float x);
