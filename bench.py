@@ -168,6 +168,9 @@ def roofline_block(name, cfg, m, exact_workload):
            "concurrent_streams": m["streams"],
            "summed_launch_time_over_frame_time": round(kernel_s / max(m["frame_dev_s"], 1e-12), 4)}
     if prof:
+        out["kernel"] = prof.get("dominant_kernel", cfg["kernel"])      # e.g. the 8-wave build of the packed walk on c5frame
+        if len(prof.get("bounce_kernels", [])) > 1:
+            out["kernels_summed"] = prof["bounce_kernels"]
         hbm_bytes_per_step = prof["hbm_bytes_per_frame"]
         out["traffic"] = round(prof["hbm_bytes_per_launch"], 1)          # 2 x FETCH_SIZE + WRITE_SIZE, per launch (guide: gfx950 rule)
         out["achieved_source"] = f"rocprofv3 PMC ({prof['_path']}, stamp matched by {prof['_matched']})"

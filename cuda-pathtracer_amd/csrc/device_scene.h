@@ -130,7 +130,8 @@ void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParam
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus);
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
-                   StatCounters* stats /* nullptr: counters compiled out */, hipStream_t s);
+                   StatCounters* stats /* nullptr: counters compiled out */,
+                   bool many_waves /* more waves than bounce_resident_waves(): an 8-wave build where there is one */, hipStream_t s);
 // render_radiosity (integrator.h:460-504): the alternative "Radiosity" integrator of renderFrame (application.h:193-197):
 // spp camera rays per pixel, first hit only, Le + per-primitive radiosity, sqrt gamma, 8-bit (+ float mean).
 void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,

@@ -350,6 +350,7 @@ struct BounceArgs {
     int* queue_out; int* count_out;
     int segments;
     StatCounters* stats;
+    int many_waves;                         // 1: more waves than the device holds at once (picks the 8-wave build of the packed walk)
 };
 
 // Per-lane path registers (the 88-byte HBM record, unpacked).
@@ -672,7 +673,7 @@ __device__ unsigned long long g_trace[16];
 #define PTMI_NODE_BURST 3
 #endif
 template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED, bool BATCH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
+__device__ __forceinline__ void bounce_phased_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
     static_assert(!(PACKED && LDS_GEOM), "the packed layout is for scenes that do not fit LDS");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -781,6 +782,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
     }
 #endif
 }
+template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED, bool BATCH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
+    bounce_phased_body<LDS_GEOM, HAS_QUADS, STATS, GUIDED, PACKED, BATCH>(a);
+}
+// The packed walk of a triangle scene, BSDF sampling, bounded to 8 waves per SIMD (64 VGPRs, 11 spilled outside the walk
+// loop): for frames with more waves than the device holds, where a wave more per SIMD is worth +5 % (whole 1 M-triangle frame
+// 1 037 -> 1 088 Msamples/s, half +4.6 %); the chain-bound case keeps the 7-wave kernel (an eighth of that frame: -5 % with
+// this one) - host/application_state.cpp decides per launch
+template <bool STATS, bool BATCH>
+__global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_packed_w8(BounceArgs a) {
+    bounce_phased_body<false, false, STATS, false, true, BATCH>(a);
+}
 
 #ifdef PTMI_TRACE_WAVES
 extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and clears the counters
@@ -813,6 +826,12 @@ static void with_bounce_gb(const BounceArgs& a, size_t lds, F&& f) {
 }
 template <bool G_, bool Q_, bool S_, bool PACKED, typename F>
 static void with_phased_gb(const BounceArgs& a, size_t lds, F&& f) {
+    if constexpr (PACKED && !Q_) {
+        if (a.many_waves && !is_guided(a)) {
+            if (a.fp.n_frames > 1) f(ptmi_bounce_packed_w8<S_, true>, lds); else f(ptmi_bounce_packed_w8<S_, false>, lds);
+            return;
+        }
+    }
     switch ((is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
         case 0: f(ptmi_bounce_phased<G_, Q_, S_, false, PACKED, false>, lds); break;
         case 1: f(ptmi_bounce_phased<G_, Q_, S_, false, PACKED, true>, lds); break;
@@ -858,16 +877,16 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
-                   StatCounters* stats, hipStream_t s) {
+                   StatCounters* stats, bool many_waves, hipStream_t s) {
     if (n_in <= 0) return;
-    BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats};
+    BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats, many_waves ? 1 : 0};
     const dim3 grid((n_in + kBlock - 1) / kBlock);
     with_bounce_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 
 // waves of the frame's bounce kernel that the device holds at once (0: unknown)
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
-    BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr};
+    BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr, 0};
     int blocks = 0;
     with_bounce_kernel(a, [&](auto kernel, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;

@@ -772,7 +772,8 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * 120;
                 launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
-                              fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr, ch.stream);
+                              fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr,
+                              wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));

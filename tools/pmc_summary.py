@@ -3,7 +3,7 @@
 
     pmc_summary.py <prof_dir> <config> <frames>
 
-Per kernel: sum and per-dispatch mean of every counter.  For the dominant kernel of the workload, per FRAME (the profile
+Per kernel: sum and per-dispatch mean of every counter.  For the bounce kernel(s) of the workload, per FRAME (the profile
 pass renders exactly <frames> frames with the timing build of the kernel):
   hbm_bytes_per_frame / _per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB - rocprofv3 reports both in KiB;
       MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a coalesced 16-B-per-lane stream ->
@@ -39,8 +39,15 @@ out = {"config": config, "frames": frames, **ptmi_buildinfo.stamps(),
 cands = [k for k in out["kernels"] if k.startswith("ptmi_bounce")]
 if cands:
     dom = max(cands, key=lambda k: out["kernels"][k].get("SQ_WAVE_CYCLES", {"sum": 0})["sum"])
-    b = out["kernels"][dom]
     out["dominant_kernel"] = dom
+    # a frame may run more than one build of the bounce kernel (the 8-wave build of the packed walk while there are more
+    # waves than wave slots, the 7-wave build for the rest of the frame): the frame's figures are sums over all of them
+    out["bounce_kernels"] = sorted(cands)
+    b = {}
+    for k in cands:
+        for c, v in out["kernels"][k].items():
+            t = b.setdefault(c, {"sum": 0.0, "dispatches": 0})
+            t["sum"] += v["sum"]; t["dispatches"] += v["dispatches"]
     if "FETCH_SIZE" in b and "WRITE_SIZE" in b:
         n = b["FETCH_SIZE"]["dispatches"]
         rd = 2.0 * b["FETCH_SIZE"]["sum"] * 1024.0; wr = b["WRITE_SIZE"]["sum"] * 1024.0
