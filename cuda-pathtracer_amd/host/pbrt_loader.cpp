@@ -9,16 +9,24 @@
 // conversion to primitives, expression by expression, so that the primitive arrays come out bit-identical to the compiled
 // reference (tests/test_pbrt_loader.py against oracle/_ref/libptmi_ref_pbrt.so and the committed goldens).
 //
-// Not restated (the load fails with a message naming the construct): "plymesh" shapes (binary/ASCII .ply reader), blackbody
+// "plymesh" shapes: the .ply reader the library drives (impl/3rdParty/rply.c through impl/semantic/Geometry.cpp:79-208) is
+// restated too - header grammar, ASCII and both binary byte orders, every scalar type with rply's range checks, lists -
+// for what the import uses: vertex x/y/z (+ nx/ny/nz), the face list vertex_indices / vertex_index, triangles only.
+//
+// Not restated (the load fails with a message naming the construct): blackbody
 // area lights (DiffuseAreaLightBB::LinRGB, a CIE table integration), "spectrum" parameters read from .spd files, shape
 // types the reference importer crashes on (it dereferences the null shape of every type but trianglemesh / plymesh / curve /
 // sphere / disk).  Rotate calls the host libm's sinf / cosf exactly as the library does (the numerics contract's sincos differs
 // from glibc's in the last bit on 2.6 % of angles, which would show in every rotated vertex).
 #include "pbrt_loader.h"
 
+#include <cctype>
 #include <cerrno>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -519,6 +527,204 @@ struct SemObject {
     std::vector<std::pair<std::shared_ptr<SemObject>, Affine>> instances;
 };
 
+// ---------------------------------------------------------------------------------------------
+// PLY files of "plymesh" shapes: pbrt::ply::parse (impl/semantic/Geometry.cpp:79-208) over rply (impl/3rdParty/rply.c)
+// ---------------------------------------------------------------------------------------------
+namespace ply {
+enum { T_I8, T_U8, T_I16, T_U16, T_I32, T_U32, T_F32, T_F64, T_LIST };
+int typeOf(const std::string& w) {                                                  // ply_type_list, rply.c:77-83
+    static const char* const names[17] = {"int8", "uint8", "int16", "uint16", "int32", "uint32", "float32", "float64",
+                                          "char", "uchar", "short", "ushort", "int", "uint", "float", "double", "list"};
+    for (int i = 0; i < 17; i++) if (w == names[i]) return i == 16 ? (int)T_LIST : i % 8;
+    return -1;
+}
+struct Property { std::string name; int type = 0, lenType = 0, valType = 0; };
+struct Element { std::string name; long count = 0; std::vector<Property> props; };
+
+struct Reader {
+    std::string buf; size_t pos = 0;
+    int mode = 2;                                                                   // 0 big endian, 1 little endian, 2 ascii
+    bool rn = false;
+    std::string word;
+    static bool blank(char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }
+    // ply_read_word (rply.c:956-1003): skip blanks, take the word, consume the ONE character behind it
+    bool readWord() {
+        while (pos < buf.size() && blank(buf[pos])) pos++;
+        if (pos >= buf.size()) return false;                                        // "Unexpected end of file"
+        const size_t b = pos;
+        while (pos < buf.size() && !blank(buf[pos])) pos++;
+        word.assign(buf, b, pos - b);
+        if (pos < buf.size()) pos++;
+        const size_t nul = word.find('\0');                                         // the library compares C strings
+        if (nul != std::string::npos) word.resize(nul);
+        return !word.empty() && word.size() < 256;                                  // WORDSIZE
+    }
+    // ply_read_line (rply.c:1013-1046): up to and including the next newline
+    bool readLine() {
+        const size_t e = buf.find('\n', pos);
+        if (e == std::string::npos) return false;
+        const size_t len = e - pos;
+        pos = e + 1;
+        return len < 1024;                                                          // LINESIZE
+    }
+    bool chunk(void* out, size_t n) {                                               // ply_read_chunk / _reverse
+        if (buf.size() - pos < n) return false;
+        unsigned char* o = static_cast<unsigned char*>(out);
+        if (mode == 1) std::memcpy(o, buf.data() + pos, n);
+        else for (size_t i = 0; i < n; i++) o[i] = (unsigned char)buf[pos + n - 1 - i];
+        pos += n;
+        return true;
+    }
+    // the idriver handlers (rply.c:1415-1530); the value travels as a double, as in the library
+    bool value(int type, double& v) {
+        if (mode == 2) {
+            if (!readWord()) return false;
+            char* end = nullptr;
+            if (type == T_F32 || type == T_F64) {
+                v = std::strtod(word.c_str(), &end);
+                if (*end) return false;
+                return type == T_F32 ? !(v < -(double)FLT_MAX || v > (double)FLT_MAX) : !(v < -DBL_MAX || v > DBL_MAX);
+            }
+            v = (double)std::strtol(word.c_str(), &end, 10);
+            if (*end) return false;
+            static const double lo[6] = {-128.0, 0.0, -32768.0, 0.0, -2147483648.0, 0.0};
+            static const double hi[6] = {127.0, 255.0, 32767.0, 65535.0, 2147483647.0, 4294967295.0};
+            return !(v > hi[type] || v < lo[type]);
+        }
+        switch (type) {
+            case T_I8: { int8_t x; if (!chunk(&x, 1)) return false; v = x; return true; }
+            case T_U8: { uint8_t x; if (!chunk(&x, 1)) return false; v = x; return true; }
+            case T_I16: { int16_t x; if (!chunk(&x, 2)) return false; v = x; return true; }
+            case T_U16: { uint16_t x; if (!chunk(&x, 2)) return false; v = x; return true; }
+            case T_I32: { int32_t x; if (!chunk(&x, 4)) return false; v = x; return true; }
+            case T_U32: { uint32_t x; if (!chunk(&x, 4)) return false; v = x; return true; }
+            case T_F32: { float x; if (!chunk(&x, 4)) return false; v = x; return true; }
+            default: return chunk(&v, 8);
+        }
+    }
+};
+
+// ply_read_header (rply.c:396-424) with its sub-parsers (:1194-1279)
+void readHeader(Reader& r, std::vector<Element>& elements, const std::string& fileName) {
+    const PbrtError bad("Unable to read the header of PLY file " + fileName);
+    const std::string& b = r.buf;
+    if (b.size() < 4 || b[0] != 'p' || b[1] != 'l' || b[2] != 'y' || !std::isspace((unsigned char)b[3])) throw bad;
+    r.rn = b[3] == '\r' && b.size() > 4 && b[4] == '\n';
+    r.pos = 3;
+    if (!r.readWord() || r.word != "format" || !r.readWord()) throw bad;
+    if (r.word == "binary_big_endian") r.mode = 0; else if (r.word == "binary_little_endian") r.mode = 1; else if (r.word == "ascii") r.mode = 2; else throw bad;
+    if (!r.readWord() || r.word != "1.0" || !r.readWord()) throw bad;
+    auto comment = [&]() {                                                          // comment / obj_info: the rest of the line
+        if (r.word != "comment" && r.word != "obj_info") return false;
+        if (!r.readLine() || !r.readWord()) throw bad;
+        return true;
+    };
+    auto property = [&]() {
+        if (r.word != "property") return false;
+        if (elements.empty()) throw bad;
+        Property p;
+        if (!r.readWord()) throw bad;
+        p.type = typeOf(r.word);
+        if (p.type < 0) throw bad;
+        if (p.type == T_LIST) {
+            if (!r.readWord()) throw bad;
+            p.lenType = typeOf(r.word);
+            if (p.lenType < 0 || !r.readWord()) throw bad;
+            p.valType = typeOf(r.word);
+            if (p.valType < 0) throw bad;
+            if (p.lenType == T_LIST || p.valType == T_LIST) throw bad;             // the library would index its handler table with it
+        }
+        if (!r.readWord()) throw bad;
+        p.name = r.word;
+        if (!r.readWord()) throw bad;
+        elements.back().props.push_back(p);
+        return true;
+    };
+    while (r.word != "end_header") {
+        if (comment()) continue;
+        if (r.word != "element") throw bad;                                         // "Unexpected token"
+        Element e;
+        if (!r.readWord()) throw bad;
+        e.name = r.word;
+        if (!r.readWord()) throw bad;
+        if (std::sscanf(r.word.c_str(), "%ld", &e.count) != 1) throw bad;
+        if (e.count < 0) throw bad;
+        if (!r.readWord()) throw bad;
+        elements.push_back(e);
+        while (property() || comment()) {}
+    }
+    if (r.rn) { if (r.pos >= b.size()) throw bad; r.pos++; }
+}
+
+// pbrt::ply::parse: positions, optional normals, triangle indices; texture coordinates are read past (the loader has no use for them)
+void parse(const std::string& fileName, std::vector<V3>& pos, std::vector<V3>& nor, std::vector<int>& idx) {
+    Reader r;
+    {
+        std::ifstream f(fileName, std::ios::binary);
+        if (!f) throw PbrtError("Couldn't open PLY file " + fileName);
+        std::ostringstream ss; ss << f.rdbuf(); r.buf = ss.str();
+    }
+    std::vector<Element> elements;
+    readHeader(r, elements, fileName);
+    long vertex_count = 0, face_count = 0;
+    bool has_normals = false, has_indices = false;
+    std::string indices_name;
+    int n_vertex_elements = 0, n_face_elements = 0;
+    for (const Element& e : elements) {
+        auto has = [&](const char* n) { for (const Property& p : e.props) if (p.name == n) return true; return false; };
+        if (e.name == "vertex") {
+            n_vertex_elements++;
+            vertex_count = e.count;
+            if (!(has("x") && has("y") && has("z"))) throw PbrtError(fileName + ": Vertex coordinate property not found!");
+            has_normals = has("nx") && has("ny") && has("nz");
+        } else if (e.name == "face") {
+            n_face_elements++;
+            face_count = e.count;
+            for (const Property& p : e.props) if (p.name == "vertex_index" || p.name == "vertex_indices") { has_indices = true; indices_name = p.name; }
+        }
+    }
+    if (n_vertex_elements > 1 || n_face_elements > 1)                               // the library sizes by the last and fills the first
+        throw PbrtError(fileName + ": more than one vertex / face element is not supported");
+    if (vertex_count == 0 || face_count == 0) throw PbrtError(fileName + ": PLY file is invalid! No face/vertex elements found!");
+    // every instance with a property takes at least one byte of data: a count beyond the file size cannot be read (the
+    // library fails at that point of the data too - after allocating for it)
+    if ((size_t)vertex_count > r.buf.size() || (size_t)face_count > r.buf.size()) throw PbrtError(fileName + ": unable to read the contents of PLY file");
+    pos.assign((size_t)vertex_count, V3());
+    if (has_normals) nor.assign((size_t)vertex_count, V3());
+    if (has_indices) idx.assign((size_t)face_count * 3, 0);
+    const PbrtError unreadable(fileName + ": unable to read the contents of PLY file");
+    for (const Element& e : elements) {                                             // ply_read (rply.c:441-454)
+        const bool is_vertex = e.name == "vertex", is_face = e.name == "face";
+        // a callback is bound to the FIRST property of its name (ply_find_property)
+        auto first = [&](const std::string& n) { for (size_t k = 0; k < e.props.size(); k++) if (e.props[k].name == n) return (long)k; return -1L; };
+        const long kx = is_vertex ? first("x") : -1, ky = is_vertex ? first("y") : -1, kz = is_vertex ? first("z") : -1;
+        const long knx = is_vertex && has_normals ? first("nx") : -1, kny = is_vertex && has_normals ? first("ny") : -1, knz = is_vertex && has_normals ? first("nz") : -1;
+        const long kidx = is_face && has_indices ? first(indices_name) : -1;
+        for (long j = 0; j < e.count; j++) {
+            for (long k = 0; k < (long)e.props.size(); k++) {
+                const Property& p = e.props[k];
+                double v = 0.0;
+                if (p.type != T_LIST) {
+                    if (!r.value(p.type, v)) throw unreadable;
+                    const float fv = (float)v;
+                    if (k == kx) pos[j].x = fv; else if (k == ky) pos[j].y = fv; else if (k == kz) pos[j].z = fv;
+                    else if (k == knx) nor[j].x = fv; else if (k == kny) nor[j].y = fv; else if (k == knz) nor[j].z = fv;
+                    continue;
+                }
+                double length = 0.0;
+                if (!r.value(p.lenType, length)) throw unreadable;
+                const long n = (long)length;
+                if (k == kidx && n != 3) throw PbrtError("Found face with vertex count different from 3, only triangles are supported");
+                for (long l = 0; l < n; l++) {
+                    if (!r.value(p.valType, v)) throw unreadable;
+                    if (k == kidx) idx[(size_t)j * 3 + l] = (int)v;
+                }
+            }
+        }
+    }
+}
+}  // namespace ply
+
 void checkTexture(const std::shared_ptr<TextureDecl>& t);
 void useTexture(const ParamSet& ps, const std::string& name) { checkTexture(ps.getTexture(name)); }
 void checkTexture(const std::shared_ptr<TextureDecl>& t) {                          // Textures.cpp:151-197
@@ -635,6 +841,7 @@ void checkMaterial(const std::shared_ptr<MaterialDecl>& m) {                    
 }
 
 struct Semantic {
+    std::string basePath;                                                           // Scene::makeGlobalFileName: basePath + relative name
     std::map<ObjectDecl*, std::shared_ptr<SemObject>> emitted;
     std::shared_ptr<SemObject> emitObject(const std::shared_ptr<ObjectDecl>& o) {   // Geometry.cpp:446-483
         auto it = emitted.find(o.get());
@@ -648,8 +855,7 @@ struct Semantic {
     }
     std::shared_ptr<Mesh> emitShape(const ShapeDecl& sh) {                          // Geometry.cpp:343-444
         const std::string& t = sh.type;
-        if (t == "plymesh") throw PbrtError("'plymesh' shapes are not supported by this loader");
-        if (t != "trianglemesh" && t != "curve" && t != "sphere" && t != "disk")
+        if (t != "trianglemesh" && t != "plymesh" && t != "curve" && t != "sphere" && t != "disk")
             throw PbrtError("shape type '" + t + "' is not handled by the reference's parser (the reference importer crashes on it)");
         checkMaterial(sh.material);
         for (const auto& it : sh.param) if (it.second.kind == Param::TEXTURE) checkTexture(it.second.texture);
@@ -665,6 +871,12 @@ struct Semantic {
             mesh->vertex = vecs("P");
             mesh->normal = vecs("N");
             if (const Param* p = sh.findKind("indices", Param::INT)) mesh->index.assign(p->i.begin(), p->i.begin() + (p->i.size() / 3) * 3);
+            for (V3& v : mesh->vertex) v = xfmPoint(sh.xfm, v);
+            for (V3& n : mesh->normal) n = xfmNormal(sh.xfm, n);
+        } else if (t == "plymesh") {                                                // emitPlyMesh, Geometry.cpp:222-236
+            mesh = std::make_shared<Mesh>();
+            mesh->material = sh.material;
+            ply::parse(basePath + sh.getString("filename"), mesh->vertex, mesh->normal, mesh->index);
             for (V3& v : mesh->vertex) v = xfmPoint(sh.xfm, v);
             for (V3& n : mesh->normal) n = xfmNormal(sh.xfm, n);
         } else if (t == "sphere" || t == "disk") {
@@ -781,6 +993,7 @@ bool loadPBRT(const std::string& filename, std::vector<Primitive>& out, std::str
         Parser parser(filename);
         parser.parseScene();
         Semantic sem;
+        sem.basePath = parser.rootNamePath;                                         // Parser.inl:906-913
         const std::shared_ptr<SemObject> world = sem.emitObject(parser.world);
         std::vector<Flat> instances;                                                // world->instances after makeSingleLevel()
         if (isSingleLevel(*world)) for (const auto& in : world->instances) instances.push_back(Flat{in.first, in.second});

@@ -51,6 +51,103 @@ def _mesh(rng):
     return s
 
 
+_PLY_TYPES = {"char": ("b", -128, 127), "uchar": ("B", 0, 255), "short": ("h", -32768, 32767), "ushort": ("H", 0, 65535),
+              "int": ("i", -2 ** 31, 2 ** 31 - 1), "uint": ("I", 0, 2 ** 32 - 1), "float": ("f", None, None), "double": ("d", None, None),
+              "int8": ("b", -128, 127), "uint8": ("B", 0, 255), "int16": ("h", -32768, 32767), "uint16": ("H", 0, 65535),
+              "int32": ("i", -2 ** 31, 2 ** 31 - 1), "uint32": ("I", 0, 2 ** 32 - 1), "float32": ("f", None, None), "float64": ("d", None, None)}
+
+
+def random_ply(rng, path, broken=0):
+    """A random PLY file for a "plymesh" shape: ASCII or either binary byte order, properties in random order with extras
+    between them, optional normals / texture coordinates, an extra element before, between or after vertex and face, comments.
+    broken: 1 = a quad among the faces, 2 = truncated data, 3 = header without format line, 4 = unknown property type,
+    5 = a vertex coordinate missing, 6 = out-of-range ASCII value (uchar 300)."""
+    import struct
+    fmt = ["ascii", "binary_little_endian", "binary_big_endian"][int(rng.integers(3))]
+    if broken == 6: fmt = "ascii"
+    nv = int(rng.integers(3, 12)); nf = int(rng.integers(1, 8))
+    ftype = lambda: ["float", "float32", "double", "float64"][int(rng.integers(4))]
+    vprops = [("x", ftype()), ("y", ftype()), ("z", ftype())]
+    if broken == 5: vprops.pop(int(rng.integers(3)))
+    if rng.random() < 0.5: vprops += [("nx", ftype()), ("ny", ftype()), ("nz", ftype())]
+    elif rng.random() < 0.2: vprops += [("nx", ftype()), ("nz", ftype())]                      # incomplete normals: ignored
+    if rng.random() < 0.4: vprops += [(["u", "s", "texture_u"][int(rng.integers(3))], "float"), (["v", "t", "texture_v"][int(rng.integers(3))], "float")]
+    for _ in range(int(rng.integers(0, 3))): vprops.append((f"extra{len(vprops)}", list(_PLY_TYPES)[int(rng.integers(16))]))
+    if rng.random() < 0.3: vprops.append(("tags", ("list", "uchar", list(_PLY_TYPES)[int(rng.integers(16))])))
+    order = rng.permutation(len(vprops)); vprops = [vprops[i] for i in order]
+    ctype = ["uchar", "uint8", "int", "ushort", "char"][int(rng.integers(5))]
+    itype = ["int", "uint", "int32", "ushort", "uchar", "float", "short"][int(rng.integers(7))]
+    fprops = [(["vertex_indices", "vertex_index"][int(rng.integers(2))], ("list", ctype, itype))]
+    if rng.random() < 0.3: fprops.insert(int(rng.integers(2)), ("flags", "uchar"))
+    if rng.random() < 0.2: fprops.append(("texcoord", ("list", "uchar", "float")))
+    elements = [("vertex", nv, vprops), ("face", nf, fprops)]
+    if rng.random() < 0.3: elements.reverse()
+    if rng.random() < 0.4: elements.insert(int(rng.integers(3)), ("edge", int(rng.integers(0, 4)), [("a", "int"), ("b", "int"), ("w", "float")]))
+    nl = "\r\n" if rng.random() < 0.15 else "\n"
+    head = ["ply"]
+    if broken != 3: head.append(f"format {fmt} 1.0")
+    if rng.random() < 0.5: head.append("comment generated for the differential test")
+    for name, n, props in elements:
+        head.append(f"element {name} {n}")
+        for pn, pt in props:
+            if isinstance(pt, tuple): head.append(f"property list {pt[1]} {pt[2]} {pn}")
+            else: head.append(f"property {'floot' if broken == 4 and pn == 'y' else pt} {pn}")
+        if rng.random() < 0.2: head.append("obj_info something")
+    head.append("end_header")
+    data = bytearray((nl.join(head) + nl).encode())
+    en = "<" if fmt == "binary_little_endian" else ">"
+    words = []
+
+    def put(t, v):
+        code = _PLY_TYPES[t][0]
+        if fmt == "ascii":
+            words.append(repr(float(v)) if code in "fd" and rng.random() < 0.7 else (f"{v:.4g}" if code in "fd" else str(int(v))))
+        else:
+            data.extend(struct.pack(en + code, float(v) if code in "fd" else int(v)))
+
+    def scalar(t):
+        code, lo, hi = _PLY_TYPES[t]
+        return float(np.float32(rng.normal(0, 2))) if code in "fd" else int(rng.integers(max(lo, -1000), min(hi, 1000) + 1))
+
+    quad_at = int(rng.integers(nf)) if broken == 1 else -1
+    for name, n, props in elements:
+        for j in range(n):
+            for pn, pt in props:
+                if isinstance(pt, tuple):
+                    if pn.startswith("vertex_ind"):
+                        k = 4 if j == quad_at else 3
+                        put(pt[1], k)
+                        for _ in range(k): put(pt[2], int(rng.integers(nv)))
+                    else:
+                        k = int(rng.integers(0, 4)); put(pt[1], k)
+                        for _ in range(k): put(pt[2], scalar(pt[2]))
+                else:
+                    put(pt, 300 if broken == 6 and pt in ("uchar", "uint8") else scalar(pt))
+            if fmt == "ascii": words.append("\n")
+    if fmt == "ascii":
+        data.extend(" ".join(words).encode())
+    if broken == 2: data = data[: max(len(data) - int(rng.integers(1, 9)), len(nl.join(head)) + 1)]
+    with open(path, "wb") as f: f.write(bytes(data))
+
+
+def random_scene_with_ply(seed, directory):
+    """random_scene plus "plymesh" shapes; writes the .ply files next to the scene and returns (scene text, expect_failure_hint)"""
+    import os
+    rng = np.random.default_rng(10_000 + seed)
+    text = random_scene(seed).rstrip("\n").split("\n")
+    assert text[-1] == "WorldEnd"
+    body = text[:-1]
+    n = int(rng.integers(1, 4))
+    for k in range(n):
+        broken = int(rng.integers(1, 7)) if rng.random() < 0.15 else 0
+        name = f"mesh{seed}_{k}.ply"
+        random_ply(rng, os.path.join(directory, name), broken)
+        line = f'Shape "plymesh" "string filename" "{name}"'
+        if rng.random() < 0.3: line = "AttributeBegin\n" + _transform(rng) + "\n" + _material(rng) + "\n" + line + "\nAttributeEnd"
+        body.append(line)
+    return "\n".join(body + ["WorldEnd"]) + "\n"
+
+
 def random_scene(seed):
     rng = np.random.default_rng(seed)
     out = ["# fuzz scene %d" % seed, f"LookAt {_vec(rng, 3)} 0 0 0 0 1 0", 'Camera "perspective" "float fov" [45]', "WorldBegin"]

@@ -13,7 +13,7 @@ import pytest
 
 import ptmi
 from oracle_binding import ref_pbrt_available, ref_pbrt_load
-from pbrt_fuzz import random_scene
+from pbrt_fuzz import random_scene, random_scene_with_ply
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PBRT = os.path.join(HERE, "golden", "pbrt")
@@ -66,6 +66,11 @@ def test_hand_checked_values():
     assert m["bsdf"][0].tolist() == [F(0.8)] * 3 and m["bsdf"][3].tolist() == [0, 0, 0]      # default material; metal: diffuse*(1-1) + 0*1
     assert np.allclose(m["bsdf"][10], [0.8 * 0.25 + 0.8 * 0.75 * 0.75, 0.3 * 0.25 + 0.3 * 0.75 * 0.75, 0.1 * 0.25 + 0.1 * 0.75 * 0.75])   # disney
     assert m["bsdf"][18].tolist() == [1, 1, 1]                            # a textured Kd counts as 1 1 1
+    y = product_load(os.path.join(PBRT, "08_plymesh.pbrt"))                 # three .ply files: ASCII, binary LE (doubles), binary BE (CRLF)
+    assert len(y["type"]) == 16
+    assert y["verts"][0, :3].tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0.25]] and np.allclose(y["normal"][0], [0, 0, 1])   # the file's nx ny nz
+    assert y["Le"][4:8].tolist() == [[4, 3, 2]] * 4 and not y["Le"][:4].any() and not y["Le"][8:].any()
+    assert np.allclose(y["bsdf"][:4], [[0.3, 0.5, 0.7]] * 4) and np.allclose(y["verts"][8, 0], [-3, 0, 0])                 # instanced under Translate -3 0 0
 
 
 def test_errors_and_unsupported_constructs(tmp_path):
@@ -74,7 +79,12 @@ def test_errors_and_unsupported_constructs(tmp_path):
         return product_load(str(f)) is None
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
     assert rejected("WorldBegin\n" + tri)                                                 # no WorldEnd: unexpected end of file
-    assert rejected('WorldBegin\nShape "plymesh" "string filename" "m.ply"\nWorldEnd\n')  # not supported here
+    assert rejected('WorldBegin\nShape "plymesh" "string filename" "m.ply"\nWorldEnd\n')  # no such file
+    (tmp_path / "bad.ply").write_text("ply\nformat ascii 2.0\nelement vertex 0\nend_header\n")
+    assert rejected('WorldBegin\nShape "plymesh" "string filename" "bad.ply"\n' + tri + "WorldEnd\n")   # header: not format 1.0
+    (tmp_path / "quad.ply").write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                                       "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    assert rejected('WorldBegin\nShape "plymesh" "string filename" "quad.ply"\nWorldEnd\n')   # triangles only, as in the library
     assert rejected('WorldBegin\nShape "cylinder" "float radius" [1]\n' + tri + "WorldEnd\n")   # the reference crashes on it
     assert rejected('WorldBegin\nAreaLightSource "diffuse" "blackbody L" [6500 1]\n' + tri + "WorldEnd\n")
     assert rejected('WorldBegin\nObjectBegin "a"\n' + tri + 'ObjectInstance "a"\nObjectEnd\nObjectInstance "a"\nWorldEnd\n')   # recursion
@@ -112,6 +122,16 @@ def test_live_against_the_compiled_reference(tmp_path):
             same(got, want, f"fuzz seed {seed}")
             n_loaded += 1
     assert n_loaded > 200
+    n_loaded = 0
+    for seed in range(200):                                   # the same scenes plus "plymesh" shapes over random .ply files
+        f = tmp_path / f"plyfuzz{seed}.pbrt"
+        f.write_text(random_scene_with_ply(seed, str(tmp_path)))
+        want, got = ref_pbrt_load(str(f)), product_load(str(f))
+        assert (want is None) == (got is None), seed
+        if want is not None:
+            same(got, want, f"ply fuzz seed {seed}")
+            n_loaded += 1
+    assert n_loaded > 120
 
 
 @pytest.mark.skipif(not ref_pbrt_available(), reason="oracle/_ref/libptmi_ref_pbrt.so not built (needs /root/reference)")
