@@ -40,6 +40,31 @@ def test_gloo_ranks_render_their_tiles_on_the_gpu(world, W, H, row_block):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,W,H,row_block,dst,what", [(2, 96, 70, 2, 0, 3), (4, 64, 64, 8, 0, 1), (3, 50, 33, 1, 2, 2), (5, 40, 21, 4, 1, 3), (5, 16, 8, 4, 0, 3)])
+def test_gather_frame_with_several_ranks_over_a_mock_transport(tmp_path, world, W, H, row_block, dst, what):
+    """ptmi_dist_init / ptmi_gather_frame / ptmi_read_frame / barrier / max-reduction with 2 - 5 ranks, every rank a process
+    with its own ptmi_ctx on the test box's one GPU.  RCCL refuses two ranks on a device, so librccl.so.1 is
+    tests/mock_rccl.cpp for these processes (files as the wire): the product's send / receive group, exact tile sizes and
+    offsets, ragged tilings (a rank without rows included), 8-bit / float / both payloads, a destination other than rank 0,
+    two gathers in flight and the placement kernel all run as they would over xGMI."""
+    root = os.path.dirname(HERE)
+    lib_dir = tmp_path / "lib"; lib_dir.mkdir()
+    wire = tmp_path / "wire"; wire.mkdir()
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
+                    os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
+    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire),
+               LD_LIBRARY_PATH=str(lib_dir) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_mock_worker.py"), str(W), str(H), "3", str(row_block), str(world), str(k),
+                               str(dst), str(what), str(tmp_path / "id.bin")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}: " + outs[k][0][-1500:] + outs[k][1][-1500:]
+    assert "mock-rccl-gather OK" in outs[dst][0]
+
+
+@pytest.mark.gpu
 def test_bench_exchange_path_through_rccl_with_one_rank():
     """bench.py's N > 1 code path (process group "nccl" = RCCL, device-to-device staging, pipelined gather) with a world of
     one rank - all that a one-GPU box can run of it - must produce a valid line."""
