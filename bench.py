@@ -271,6 +271,9 @@ def main():
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: ranks share devices and the gather
     # goes through host memory with gloo.  Never used for reported numbers.
     ap.add_argument("--rehearse-gloo", action="store_true", help=argparse.SUPPRESS)
+    # the same with the frame exchange going through ptmi_gather_frame as on N GPUs (torch's own group on gloo): for a
+    # librccl.so.1 that accepts ranks sharing a device - tests/mock_rccl.cpp.  Never used for reported numbers.
+    ap.add_argument("--rehearse-shared-gpu", action="store_true", help=argparse.SUPPRESS)
     # exercise the RCCL code path (comm init, gather, barrier) even with one rank; never used for reported numbers
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -286,14 +289,15 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {n_gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    device_index = local_rank % torch.cuda.device_count() if args.rehearse_gloo else local_rank
+    shared = args.rehearse_gloo or args.rehearse_shared_gpu
+    device_index = local_rank % torch.cuda.device_count() if shared else local_rank
     torch.cuda.set_device(device_index)
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_gloo:
+        if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
@@ -368,7 +372,7 @@ def main():
     def reduce_max(elapsed):
         if not use_dist:
             return elapsed
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if args.rehearse_gloo else torch.device("cuda", device_index))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if shared else torch.device("cuda", device_index))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -43,8 +44,14 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl r;
     if (r.handle) return r;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+    // PTMI_RCCL_LIB: the file to load instead (a process that has torch in it already holds torch's librccl.so.1, which a bare
+    // name would resolve to; the tests' transport stand-in, tests/mock_rccl.cpp, is given by path)
+    const char* names[] = {std::getenv("PTMI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        r.handle = dlopen(n, RTLD_NOW | (n == names[0] ? RTLD_LOCAL : RTLD_GLOBAL));      // a stand-in must not interpose on anyone else's nccl*
+        if (r.handle) break;
+    }
     if (!r.handle) throw DistError(std::string("cannot load librccl.so.1: ") + dlerror());
     auto sym = [&](const char* name) {
         void* p = dlsym(r.handle, name);

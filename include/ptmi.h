@@ -240,7 +240,8 @@ int ptmi_host_image(const ptmi_ctx*, const unsigned char** rgb8, uint64_t* n_byt
  * (ptmi_update_resolution with ptmi_tiling {n_ranks, rank, row_block}); no data-path collective.  The ONE exchange step
  * of a frame is ptmi_gather_frame: every rank's tile goes to dst_rank over RCCL (direct ncclSend per peer /
  * N-1 ncclRecv on dst in one group: xGMI is point-to-point, every peer pushes over its own link), exact tile sizes, and
- * a kernel on dst places the rows into the whole frame.  librccl.so.1 is loaded on the first ptmi_dist_* call.
+ * a kernel on dst places the rows into the whole frame.  librccl.so.1 is loaded on the first ptmi_dist_* call
+ * (environment PTMI_RCCL_LIB = a file to load in its place).
  *
  *   rank 0:  ptmi_dist_unique_id(id)  -> ship the 128 bytes to every rank (MPI, a file, torch.distributed, ...)
  *   all   :  ptmi_dist_init(ctx, id, n_ranks, rank)        (collective: ncclCommInitRank)

@@ -65,6 +65,30 @@ def test_gather_frame_with_several_ranks_over_a_mock_transport(tmp_path, world, 
 
 
 @pytest.mark.gpu
+def test_bench_with_three_ranks_over_the_mock_transport(tmp_path):
+    """bench.py --gpus 3 exactly as the driver launches it (torch.distributed.run, one process per rank), the frame exchange
+    through ptmi_gather_frame - with the three ranks sharing the test box's GPU, librccl.so.1 = tests/mock_rccl.cpp and torch's
+    own group on gloo.  The line must be a valid weak-scaling line of three ranks."""
+    import json
+    root = os.path.dirname(HERE)
+    lib_dir = tmp_path / "lib"; lib_dir.mkdir()
+    wire = tmp_path / "wire"; wire.mkdir()
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
+                    os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
+    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire), PTMI_RCCL_LIB=str(lib_dir / "librccl.so.1"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1",
+           "--rehearse-shared-gpu", "--no-cpu", "--spp", "4", "--side", "192"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert 0.0 < line["roofline"]["frac"] <= 1.0
+    assert any(f.startswith("mock-") for f in os.listdir(wire))                      # the exchange really went over the mock
+
+
+@pytest.mark.gpu
 def test_bench_exchange_path_through_rccl_with_one_rank():
     """bench.py's N > 1 code path (process group "nccl" = RCCL, device-to-device staging, pipelined gather) with a world of
     one rank - all that a one-GPU box can run of it - must produce a valid line."""
