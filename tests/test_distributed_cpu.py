@@ -40,9 +40,10 @@ def test_gloo_ranks_render_their_tiles_on_the_gpu(world, W, H, row_block):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,W,H,row_block,dst,what", [(2, 96, 70, 2, 0, 3), (4, 64, 64, 8, 0, 1), (3, 50, 33, 1, 2, 2), (5, 40, 21, 4, 1, 3), (5, 16, 8, 4, 0, 3)])
+@pytest.mark.parametrize("world,W,H,row_block,dst,what", [(2, 96, 70, 2, 0, 3), (4, 64, 64, 8, 0, 1), (3, 50, 33, 1, 2, 2), (4, 40, 21, 4, 1, 3), (4, 16, 8, 4, 0, 3)])
 def test_gather_frame_with_several_ranks_over_a_mock_transport(tmp_path, world, W, H, row_block, dst, what):
-    """ptmi_dist_init / ptmi_gather_frame / ptmi_read_frame / barrier / max-reduction with 2 - 5 ranks, every rank a process
+    """ptmi_dist_init / ptmi_gather_frame / ptmi_read_frame / barrier / max-reduction with 2 - 4 ranks (the GPU box allows six
+    processes on its card, this one included), every rank a process
     with its own ptmi_ctx on the test box's one GPU.  RCCL refuses two ranks on a device, so librccl.so.1 is
     tests/mock_rccl.cpp for these processes (files as the wire): the product's send / receive group, exact tile sizes and
     offsets, ragged tilings (a rank without rows included), 8-bit / float / both payloads, a destination other than rank 0,
