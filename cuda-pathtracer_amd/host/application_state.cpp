@@ -693,10 +693,13 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // ~4 000 segments per second; BASELINE's 2048 spp x 8 bounces = 16 384 segments at most = ONE 1.45 s launch per chunk.  A
     // boundary in mid-frame is dear: with 8 192 the same frame took 1.58 s)
     constexpr int kRestOfFrameSegments = 65536;
-    // (the phased kernels only: the sweep's cost per segment does not shrink with its living lanes, so its waves want the
-    // compaction of every 32nd segment to the end - c2 -7 %, c3 -8 % with the rule applied to it)
+    // The sweep's cost per segment does not shrink with its living lanes, so its waves want the compaction of every 32nd
+    // segment for longer: with the phased kernels' threshold c2 loses 7 %, c3 8 %; at 0.3 x the wave slots a small frame
+    // gains (cbox 256^2 +14 %, 362^2 +15 %; 512^2 = 0.5 x the slots -11 % with one launch) and c2's last stretch +0.5 %.
     const int trav = g.scene.d_scene.traversal;
-    const long long wave_slots = g.config.segments_per_launch > 0 || (trav != TRAVERSAL_PHASED && trav != TRAVERSAL_PACKED)
+    const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED;
+    const long long fit_pct = phased ? 120 : 30;
+    const long long wave_slots = g.config.segments_per_launch > 0 || !(phased || trav == TRAVERSAL_SWEEP)
                                      ? 0 : bounce_resident_waves(g.scene.d_scene, fp, g.config.collect_stats, g.n_cus);
     hipStream_t s = r.stream;
     // whatever way this function is left, nothing of this frame is still in flight (an exception thrown between two
@@ -769,11 +772,11 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
                 long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
                 for (int k = 0; k < r.n_chunks; k++) active += run[k].finished ? 0 : run[k].bound;
-                const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * 120;
+                const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * fit_pct;
                 launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
                               fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr,
-                              wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream);
+                              phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
