@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help=argparse.SUPPRESS)          # for quick experiments only
     ap.add_argument("--side", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--streams", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather", choices=("rgb8", "radiance", "both"), default="rgb8", help="what the frame-end gather moves (N > 1)")
     ap.add_argument("--pipeline", action="store_true", help="render the K steps as ONE pipelined batch (ptmi_render_frames) instead of one "
@@ -311,13 +312,15 @@ def main():
         cfg["width"] = cfg["height"] = args.side
     if args.spp:
         cfg["spp"] = args.spp
-    exact = not args.side and not args.spp and not args.segments and world == 1
+    exact = not args.side and not args.spp and not args.segments and not args.streams and world == 1
     row_block = 2 if name == "c2" else 8             # 2-row blocks: every rank gets exactly side/N rows at N = 1, 2, 4, 8
 
     r = ptmi.Renderer(device_index)
     load_scene(r, cfg["scene"])
 
     def allocate(c):
+        if args.streams:
+            r.set_config(streams=args.streams)                  # chunks are dealt at update_resolution
         if c["tiling"] and world == 1:
             n_r, rk, rb = c["tiling"]
             r.update_resolution(c["width"], c["height"], n_ranks=n_r, rank=rk, row_block=rb)      # re-seeds the RNG streams
