@@ -70,7 +70,7 @@ void ptmi_default_config(ptmi_config* c) {
     const AppConfig d;
     c->spp = d.spp; c->max_depth = d.max_depth; c->sampling_mode = (int)d.sampling_mode; c->seed_base = d.seed_base;
     c->segments_per_launch = 0; c->collect_stats = 0; c->wave_tiles = 0; c->streams = 0; c->mis_bsdf_fraction = d.mis_bsdf_fraction; c->integrator = 0;
-    c->download_image = 0;
+    c->download_image = 0; c->fast_tree = 0;
 }
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
@@ -387,6 +387,7 @@ int ptmi_set_config(ptmi_ctx* c, const ptmi_config* cfg) {
         c->app.render.allow_tile8 = cfg->wave_tiles != 0;
         c->app.render.want_chunks = cfg->streams;
         c->app.render.download_image = cfg->download_image != 0;
+        a.fast_tree = cfg->fast_tree != 0;
     });
 }
 
@@ -588,6 +589,75 @@ int ptmi_debug_set_packed_top(ptmi_ctx* c, int top_records, int* n_top, int* top
         if (s.d_nodes) { s.buildPacked(); s.chooseTraversal(); }
         if (n_top) *n_top = s.d_scene.n_top;
         if (top_depth) *top_depth = s.d_scene.top_depth;
+    });
+}
+
+int ptmi_debug_set_fast_tree(ptmi_ctx* c, int max_leaf, float c_trav, float c_tri, int top_nodes, int* n_nodes, int* depth, int* n_top) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(max_leaf >= 1 && max_leaf <= kWideMaxLeaf, "max_leaf must be 1..3");
+        need(c_trav >= 0.0f && c_tri > 0.0f, "c_trav must be >= 0 and c_tri > 0");
+        need(top_nodes >= 0 && top_nodes <= 600, "top_nodes must be in [0, 600] (75 KB of LDS)");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        SceneState& s = c->app.scene;
+        s.wide_params.max_leaf = max_leaf; s.wide_params.c_trav = c_trav; s.wide_params.c_tri = c_tri; s.wide_top_nodes = top_nodes;
+        if (s.d_nodes && !s.num_quads) s.buildFast();
+        if (n_nodes) *n_nodes = s.d_scene.w_nodes;
+        if (depth) *depth = s.d_scene.w_depth;
+        if (n_top) *n_top = s.d_scene.w_top;
+    });
+}
+
+int ptmi_debug_intersect_fast(ptmi_ctx* c, int n, const float* o, const float* d, float t_min, float t_max,
+                              int* hit, int* prim, float* t, uint64_t* counts) {
+    return guarded([&] {
+        need(c && o && d && hit && prim && t, "NULL argument");
+        need(c->app.scene.d_nodes != nullptr, "no scene loaded");
+        need(n > 0, "n must be positive");
+        PTMI_HIP(hipSetDevice(c->app.device_id));
+        if (!c->app.scene.fastReady()) c->app.scene.buildFast();
+        DevBuf<float> d_o(3 * (size_t)n), d_d(3 * (size_t)n), d_t(n);
+        DevBuf<int> d_hit(n), d_prim(n);
+        DevBuf<unsigned long long> d_cnt(2);
+        PTMI_HIP(hipMemset(d_cnt.p, 0, 2 * sizeof(unsigned long long)));
+        d_o.upload(o, 3 * (size_t)n); d_d.upload(d, 3 * (size_t)n);
+        launch_debug_intersect_wide(c->app.scene.d_scene, n, d_o.p, d_d.p, t_min, t_max, d_hit.p, d_prim.p, d_t.p, d_cnt.p, c->app.render.stream);
+        PTMI_HIP(hipGetLastError());
+        PTMI_HIP(hipStreamSynchronize(c->app.render.stream));
+        d_hit.download(hit, n); d_prim.download(prim, n); d_t.download(t, n);
+        if (counts) { unsigned long long h[2]; d_cnt.download(h, 2); counts[0] = h[0]; counts[1] = h[1]; }
+    });
+}
+
+int ptmi_host_fast_tree_build(ptmi_host_scene* s, int max_leaf, float c_trav, float c_tri, int* n_nodes, int* depth, double* sah) {
+    return guarded([&] {
+        need(s != nullptr, "scene is NULL");
+        need(max_leaf >= 1 && max_leaf <= kWideMaxLeaf, "max_leaf must be 1..3");
+        need(c_trav >= 0.0f && c_tri > 0.0f, "c_trav must be >= 0 and c_tri > 0");
+        SceneState& sc = s->scene;
+        sc.wide_params.max_leaf = max_leaf; sc.wide_params.c_trav = c_trav; sc.wide_params.c_tri = c_tri;
+        try { buildWideBVH(sc.h_primitives, sc.wide_params, sc.h_wide); }
+        catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
+        if (n_nodes) *n_nodes = sc.h_wide.n_nodes;
+        if (depth) *depth = sc.h_wide.depth;
+        if (sah) *sah = sc.h_wide.sah;
+    });
+}
+int ptmi_host_fast_tree_intersect(const ptmi_host_scene* s, int n, const float* o, const float* d, float t_min, float t_max,
+                                  int* prim, float* t, uint64_t* counts) {
+    return guarded([&] {
+        need(s && o && d && prim && t, "NULL argument");
+        const SceneState& sc = s->scene;
+        need(!sc.h_wide.empty(), "no fast tree built (ptmi_host_fast_tree_build)");
+        std::vector<int> ref_slot(sc.h_primitives.size());
+        for (size_t k = 0; k < sc.bvh_indices.size(); k++) ref_slot[(size_t)sc.bvh_indices[k]] = (int)k;
+        WideWalkCounters cn;
+        for (int i = 0; i < n; i++) {
+            float th = 0.0f;
+            prim[i] = wideIntersectHost(sc.h_wide, sc.h_primitives, ref_slot, v3(o + 3 * i), v3(d + 3 * i), t_min, t_max, th, &cn);
+            t[i] = prim[i] >= 0 ? th : 0.0f;
+        }
+        if (counts) { counts[0] = cn.node_visits; counts[1] = cn.prim_tests; counts[2] = cn.max_stack; }
     });
 }
 

@@ -58,6 +58,16 @@ struct DeviceScene {
     const float4* mtab = nullptr;      // distinct (Kd, Ke) pairs, 2 float4 per row
     const int* load_index = nullptr;   // leaf-order slot -> load-order primitive index (guided sampling reads cdfs through it)
     int n_top = 0, top_depth = 0;      // positions < n_top (the nodes of depth <= top_depth, level by level) are staged into LDS
+    // TRAVERSAL_WIDE (opt-in fast tree, csrc/wide_bvh.h): 8-wide nodes of 128 bytes, breadth-first; per-triangle arrays in the
+    // fast tree's own leaf order ("fast order")
+    const uint4* wnodes = nullptr;     // 8 uint4 per node
+    int w_nodes = 0, w_top = 0;        // nodes < w_top (whole levels) are staged into LDS by every workgroup
+    int w_depth = 0;                   // levels of the tree = entries of the walk's per-lane LDS stack
+    const float* wprims = nullptr;     // 9 floats (v0, e1, e2) per fast-order triangle
+    const float4* wmats = nullptr;     // (normal.xyz, bits(row of mtab)) per fast-order triangle
+    const float4* wmtab = nullptr;     // distinct (Kd, Ke) pairs, 2 float4 per row
+    const int* wload_index = nullptr;  // fast order -> load-order primitive index
+    const int* wref_slot = nullptr;    // fast order -> reference leaf-order slot (equal-t hits keep the smaller one, scene.h:89-90)
 };
 // PACKED LAYOUT.  On the 1 M-triangle scene the phased walk is bound by the rate at which L2 misses are served (it runs at
 // the same speed with 2 and with 7 waves per SIMD, with and without half of its node reads moved to LDS): what counts is the
@@ -82,6 +92,8 @@ enum TraversalMode {
     TRAVERSAL_PHASED = 3,  // large scenes: the stackless per-lane walk with wave-scheduled phases (ptmi_bounce_phased):
                            // lanes whose ray ends early shade and start their next segment instead of idling
     TRAVERSAL_PACKED = 4,  // scenes too large for LDS: PHASED over the packed layout (sibling pairs, 36-byte triangles)
+    TRAVERSAL_WIDE = 5,    // opt-in (ptmi_config.fast_tree): PHASED over the 8-wide SAH tree of csrc/wide_bvh.h; the one walk
+                           // that does NOT visit the reference's nodes - same triangles, same hit arithmetic, other boxes
 };
 
 struct PathState {
@@ -186,6 +198,8 @@ void launch_filter_pdfs(int n, const float* d_rgb, const float* d_counts, float*
 // test hooks
 void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
                             int* hit, int* prim, float* t, float* p, float* nrm, hipStream_t s);
+void launch_debug_intersect_wide(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
+                                 int* hit, int* prim, float* t, unsigned long long* counts /* 2, may be nullptr */, hipStream_t s);
 void launch_debug_rng(const uint32_t* d_jump, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out, hipStream_t s);
 void launch_debug_rcp(unsigned int first_bits, unsigned long long count, unsigned long long* d_out, hipStream_t s);
 void launch_debug_cosine(int n, const float* normals, const float* u, const float* v, float* out, hipStream_t s);

@@ -795,6 +795,119 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
     bounce_phased_body<false, false, STATS, false, true, BATCH>(a);
 }
 
+
+// ---- ptmi_bounce_wide: the opt-in fast tree (csrc/wide_bvh.h) --------------------------------------------------------------
+// The phased scheduling of ptmi_bounce_phased over the 8-wide SAH tree.  A NODE step enters ONE inner child: it takes the
+// front-most pending child of the lane's current group (or pops a group), fetches that child's 128-byte node - one L2 line,
+// or LDS for the top levels - and decides its eight children at once: hit inner children become the new current group, the
+// triangles of hit leaf children a 24-bit mask that the following PRIM steps test one by one.  Stack: one (child_base,
+// imask << 8 | pending) pair per tree level in LDS, entry e of lane l at stack[e * kBlock + l] - conflict-free whatever e.
+// The triangle test is the exact walk's (mt_hit = mt_accept's arithmetic); equal-t hits keep the smaller reference slot.
+template <bool STATS, bool GUIDED, bool BATCH>
+__device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
+    extern __shared__ float4 smem[];
+    const int n_in = a.count_in ? *a.count_in : a.n_in;
+    if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
+    const int n_top = a.sc.w_top;
+    uint4* top = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < 8 * n_top; i += kBlock) top[i] = a.sc.wnodes[i];
+    uint2* stack = reinterpret_cast<uint2*>(top + 8 * n_top) + threadIdx.x;
+    __syncthreads();
+    const MatSource ms = MatSource{a.sc.wmats, a.sc.wmtab, a.sc.wload_index};
+    if (GUIDED) fill_grid_solid_angles();
+
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < n_in;
+    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
+    bool alive = active;
+    PathRegs p = {};
+    if (active) load_path(a.st, a.tm, slot, p);
+    LaneCounters cn = {0, 0, 0, 0, 0};
+
+    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
+    const float t_min = 1e-4f, t_lo = mt_t_lo(t_min);
+    int phase = alive ? PH_NODE : PH_DONE;
+    int segs_left = a.segments;
+    int slot_hit = -1, sp = 0;
+    float closest_t = FLT_MAX;
+    f3 inv = mk3(wide_inv(p.d.x), wide_inv(p.d.y), wide_inv(p.d.z));
+    uint32_t octinv = wide_octinv(inv);
+    uint32_t g_base = 0u, g_bits = (1u << 8) | (1u << octinv);      // the root: slot 0 of a virtual parent
+    uint32_t t_base = 0u, t_mask = 0u;
+    if (STATS && alive) cn.rays++;
+
+    while (true) {
+        const int c_node = __popcll(__ballot(phase == PH_NODE));
+        const int c_prim = __popcll(__ballot(phase == PH_PRIM));
+        const int c_shade = __popcll(__ballot(phase == PH_SHADE));
+        if (c_node + c_prim + c_shade == 0) break;
+        if (c_node >= c_prim && c_node >= c_shade) {
+            if (phase == PH_NODE) {
+                if ((g_bits & 0xffu) == 0u) { sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y; }
+                const int bit = 31 - __clz((int)(g_bits & 0xffu));
+                g_bits ^= 1u << bit;
+                const uint32_t child = (uint32_t)bit ^ octinv;
+                const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
+                if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
+                uint4 q0, q1, q2, q3, q4, q5, q6;
+                if ((int)ni < n_top) {
+                    const uint4* q = top + 8 * ni;
+                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
+                    if (STATS) cn.top_visits++;
+                } else {
+                    const uint4* q = a.sc.wnodes + 8 * (size_t)ni;
+                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
+                }
+                if (STATS) cn.node_visits++;
+                const WideStep st = wide_node_test(q0, q1, q2, q3, q4, q5, q6, p.o, inv, octinv, t_min, closest_t);
+                g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
+                t_base = st.tri_base; t_mask = st.tris;
+                if (t_mask) phase = PH_PRIM;
+                else if ((g_bits & 0xffu) == 0u && sp == 0) phase = PH_SHADE;
+            }
+        } else if (c_prim >= c_shade) {
+            if (phase == PH_PRIM) {
+                const int k = (int)t_base + __ffs((int)t_mask) - 1;
+                t_mask &= t_mask - 1u;
+                if (STATS) cn.prim_tests++;
+                const f3p* r = reinterpret_cast<const f3p*>(a.sc.wprims) + 3 * (size_t)k;
+                const f3p v0 = r[0], e1 = r[1], e2 = r[2];
+                float tt = 0.0f;
+                const bool ok = mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), p.o, p.d, 1e-8f, t_lo, tt);
+                if (ok) {
+                    if (tt < closest_t) { closest_t = tt; slot_hit = k; }
+                    else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
+                        if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
+                    }
+                }
+                if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : PH_SHADE;
+            }
+        } else {
+            if (phase == PH_SHADE) {
+                const bool more = shade_step<STATS, GUIDED, true, BATCH>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn, slot);
+                segs_left--;
+                if (!more) { alive = false; phase = PH_DONE; }
+                else if (segs_left == 0) phase = PH_DONE;
+                else {
+                    slot_hit = -1; closest_t = FLT_MAX; sp = 0; t_mask = 0u;
+                    inv = mk3(wide_inv(p.d.x), wide_inv(p.d.y), wide_inv(p.d.z));
+                    octinv = wide_octinv(inv);
+                    g_base = 0u; g_bits = (1u << 8) | (1u << octinv);
+                    phase = PH_NODE;
+                    if (STATS) cn.rays++;
+                }
+            }
+        }
+    }
+
+    if (active) store_path(a.st, slot, p);
+    finish_launch<STATS>(a, alive, slot, cn);
+}
+template <bool STATS, bool GUIDED, bool BATCH>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
+    bounce_wide_body<STATS, GUIDED, BATCH>(a);
+}
+
 #ifdef PTMI_TRACE_WAVES
 extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and clears the counters
     unsigned long long z[16] = {};
@@ -804,6 +917,7 @@ extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and cle
 #endif
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
+    if (sc.traversal == TRAVERSAL_WIDE) return (size_t)sc.w_top * kWideNodeDwords * 4 + (size_t)sc.w_depth * kBlock * sizeof(uint2);
     size_t b = 0;
     const bool geom = sc.lds_resident || sc.traversal == TRAVERSAL_SWEEP;
     if (geom) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);
@@ -869,6 +983,18 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
             if (sc.lds_resident) with_bounce_qs<3, true>(a, lds, f); else with_bounce_qs<3, false>(a, lds, f);
             break;
         case TRAVERSAL_PACKED: with_bounce_qs<4, false>(a, (size_t)sc.n_top * 2 * sizeof(float4), f); break;
+        case TRAVERSAL_WIDE:
+            switch ((a.stats ? 4 : 0) | (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
+                case 0: f(ptmi_bounce_wide<false, false, false>, lds); break;
+                case 1: f(ptmi_bounce_wide<false, false, true>, lds); break;
+                case 2: f(ptmi_bounce_wide<false, true, false>, lds); break;
+                case 3: f(ptmi_bounce_wide<false, true, true>, lds); break;
+                case 4: f(ptmi_bounce_wide<true, false, false>, lds); break;
+                case 5: f(ptmi_bounce_wide<true, false, true>, lds); break;
+                case 6: f(ptmi_bounce_wide<true, true, false>, lds); break;
+                default: f(ptmi_bounce_wide<true, true, true>, lds); break;
+            }
+            break;
         default:
             if (sc.lds_resident) with_bounce_qs<TRAVERSAL_STACK, true>(a, lds, f); else with_bounce_qs<TRAVERSAL_STACK, false>(a, lds, f);
             break;
@@ -1039,6 +1165,62 @@ void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const 
         default: PTMI_DBG(TRAVERSAL_STACK, true); break;
     }
 #undef PTMI_DBG
+}
+
+// Closest hit through the fast tree for n rays (test hook): the walk of ptmi_bounce_wide, lane by lane, without the phases
+__global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_wide_k(DeviceScene sc, int n, const float* o, const float* d, float t_min,
+                                                                      float t_max, int* hit, int* prim, float* t_out,
+                                                                      unsigned long long* counts /* [0] node visits [1] triangle tests */) {
+    extern __shared__ float4 smem[];
+    uint2* stack = reinterpret_cast<uint2*>(smem) + threadIdx.x;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const f3 inv = mk3(wide_inv(rd.x), wide_inv(rd.y), wide_inv(rd.z));
+    const uint32_t octinv = wide_octinv(inv);
+    const float t_lo = mt_t_lo(t_min);
+    float closest_t = t_max;
+    int slot_hit = -1, sp = 0;
+    uint32_t g_base = 0u, g_bits = (1u << 8) | (1u << octinv);
+    unsigned int nv = 0, pt = 0;
+    while (true) {
+        if ((g_bits & 0xffu) == 0u) {
+            if (sp == 0) break;
+            sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y;
+        }
+        const int bit = 31 - __clz((int)(g_bits & 0xffu));
+        g_bits ^= 1u << bit;
+        const uint32_t child = (uint32_t)bit ^ octinv;
+        const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
+        if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
+        const uint4* q = sc.wnodes + 8 * (size_t)ni;
+        nv++;
+        const WideStep st = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], ro, inv, octinv, t_min, closest_t);
+        uint32_t tris = st.tris;
+        while (tris) {
+            const int k = (int)st.tri_base + __ffs((int)tris) - 1;
+            tris &= tris - 1u;
+            pt++;
+            const f3p* r = reinterpret_cast<const f3p*>(sc.wprims) + 3 * (size_t)k;
+            const f3p v0 = r[0], e1 = r[1], e2 = r[2];
+            float tt = 0.0f;
+            if (mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), ro, rd, 1e-8f, t_lo, tt)) {
+                if (tt < closest_t) { closest_t = tt; slot_hit = k; }
+                else if (tt == closest_t && slot_hit >= 0 && sc.wref_slot[k] < sc.wref_slot[slot_hit]) slot_hit = k;
+            }
+        }
+        g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
+    }
+    hit[i] = slot_hit >= 0 ? 1 : 0;
+    prim[i] = slot_hit >= 0 ? sc.wload_index[slot_hit] : -1;
+    t_out[i] = slot_hit >= 0 ? closest_t : 0.0f;
+    if (counts) { atomicAdd(&counts[0], (unsigned long long)nv); atomicAdd(&counts[1], (unsigned long long)pt); }
+}
+void launch_debug_intersect_wide(const DeviceScene& sc, int n, const float* o, const float* d, float t_min, float t_max,
+                                 int* hit, int* prim, float* t, unsigned long long* counts, hipStream_t s) {
+    if (n <= 0) return;
+    const size_t lds = (size_t)sc.w_depth * kBlock * sizeof(uint2);
+    hipLaunchKernelGGL(ptmi_debug_intersect_wide_k, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, counts);
 }
 
 __global__ void ptmi_debug_rng_k(const uint32_t* __restrict__ jump, unsigned long long seed_base, int n_pixels,

@@ -2,6 +2,7 @@
 // Compile with -ffp-contract=off (see include/ptmi_math.h, pt_vec.h).
 #pragma once
 #include "device_scene.h"
+#include "wide_bvh.h"
 
 #include <float.h>
 
@@ -84,6 +85,22 @@ __device__ __forceinline__ bool mt_accept(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d,
     float m = min3_raw(m1, v, 1.0f - (u + v));
     m = min_raw(m, t - t_lo);
     return (m >= 0.0f) & (t < closest_t);          // t <= t_max && scene.h:90's strict t < closest_t; false for a NaN t
+}
+// The same test without the comparison against closest_t: the fast tree's walk (csrc/wide_bvh.h) needs to see t == closest_t
+__device__ __forceinline__ bool mt_hit(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float eps_for_a, float t_lo, float& t) {
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    const float f = rcp_exact_normal(a);
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    const float m1 = min3_raw(fabsf(a) - eps_for_a, u, 1.0f - u);
+    if (!__any(m1 >= 0.0f)) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    t = f * dot(edge2, q);
+    float m = min3_raw(m1, v, 1.0f - (u + v));
+    m = min_raw(m, t - t_lo);
+    return m >= 0.0f;
 }
 // t_lo for a given t_min:  t > 1e-8f && t >= t_min  <=>  t >= t_lo
 __device__ __forceinline__ float mt_t_lo(float t_min) {

@@ -89,6 +89,7 @@ void SceneState::cleanup() {
     if (d_precomputed_cdfs) (void)hipFree(d_precomputed_cdfs);
     if (d_radiosity) (void)hipFree(d_radiosity);
     freePacked();
+    freeFast();
     d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr; d_radiosity = nullptr;
     h_precomputed_cdfs.clear(); h_radiosity_grids.clear(); h_count_grids.clear(); h_filtered_formfactor.clear(); h_filtered_radiosity.clear();
     d_scene = DeviceScene();
@@ -301,6 +302,65 @@ void SceneState::buildPacked() {
     if (!num_quads) d_gprims = (float*)upload_vec(gp.data(), gp.size() * sizeof(float), "d_gprims");
     d_scene.gnodes = d_gnodes; d_scene.n_pos = n_pos; d_scene.gprims = d_gprims; d_scene.gmats = d_gmats; d_scene.mtab = d_mtab;
     d_scene.load_index = d_load_index; d_scene.n_top = n_top; d_scene.top_depth = top_depth;
+}
+
+void SceneState::freeFast() {
+    void* ptrs[] = {d_wnodes, d_wprims, d_wmats, d_wmtab, d_wload_index, d_wref_slot};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_wnodes = nullptr; d_wprims = nullptr; d_wmats = d_wmtab = nullptr; d_wload_index = d_wref_slot = nullptr;
+    h_wide.clear();
+    d_scene.wnodes = nullptr; d_scene.w_nodes = d_scene.w_top = d_scene.w_depth = 0; d_scene.wprims = nullptr; d_scene.wmats = nullptr;
+    d_scene.wmtab = nullptr; d_scene.wload_index = nullptr; d_scene.wref_slot = nullptr;
+}
+
+// The opt-in fast tree (csrc/wide_bvh.h): same triangles, same hit arithmetic, own boxes.  Per-triangle arrays are re-ordered
+// into the fast tree's leaf order; wref_slot keeps every triangle's reference leaf-order slot for the equal-t rule.
+void SceneState::buildFast() {
+    freeFast();
+    if (!d_nodes) throw ArgError("fast tree: no scene loaded");
+    if (num_quads) throw ArgError("fast tree: triangle scenes only (load with convert_quads)");
+    try { buildWideBVH(h_primitives, wide_params, h_wide); }
+    catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
+    if (h_wide.depth > 48) { h_wide.clear(); throw ArgError("fast tree: deeper than 48 levels"); }
+    const int n = (int)h_primitives.size();
+    auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
+    std::vector<int> ref_slot_of_load((size_t)n), ref_slot((size_t)n);
+    for (int k = 0; k < n; k++) ref_slot_of_load[bvh_indices[k]] = k;
+    std::map<std::array<uint32_t, 6>, int> rows;
+    std::vector<float4> wm((size_t)n), tab;
+    std::vector<float> wp((size_t)9 * n);
+    for (int k = 0; k < n; k++) {
+        const int li = h_wide.tri_load_index[k];
+        const Primitive& p = h_primitives[li];
+        ref_slot[k] = ref_slot_of_load[li];
+        std::array<uint32_t, 6> key;
+        const float kv[6] = {p.bsdf.x, p.bsdf.y, p.bsdf.z, p.Le.x, p.Le.y, p.Le.z};
+        std::memcpy(key.data(), kv, sizeof kv);
+        auto it = rows.find(key);
+        if (it == rows.end()) {
+            it = rows.emplace(key, (int)rows.size()).first;
+            tab.push_back(make_float4(p.bsdf.x, p.bsdf.y, p.bsdf.z, 0.0f)); tab.push_back(make_float4(p.Le.x, p.Le.y, p.Le.z, 0.0f));
+        }
+        wm[k] = make_float4(p.normal.x, p.normal.y, p.normal.z, bits(it->second));
+        const f3 e1 = p.v[1] - p.v[0], e2 = p.v[2] - p.v[0];             // the float subtraction the reference does per test
+        const float rec[9] = {p.v[0].x, p.v[0].y, p.v[0].z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z};
+        std::memcpy(&wp[(size_t)9 * k], rec, sizeof rec);
+    }
+    auto upload_vec = [&](const void* src, size_t bytes, const char* name) {
+        void* d = hipMallocSafe(bytes, name);
+        PTMI_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        return d;
+    };
+    d_wnodes = (uint4*)upload_vec(h_wide.nodes.data(), h_wide.nodes.size() * sizeof(uint32_t), "d_wnodes");
+    d_wprims = (float*)upload_vec(wp.data(), wp.size() * sizeof(float), "d_wprims");
+    d_wmats = (float4*)upload_vec(wm.data(), wm.size() * sizeof(float4), "d_wmats");
+    d_wmtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_wmtab");
+    d_wload_index = (int*)upload_vec(h_wide.tri_load_index.data(), (size_t)n * sizeof(int), "d_wload_index");
+    d_wref_slot = (int*)upload_vec(ref_slot.data(), (size_t)n * sizeof(int), "d_wref_slot");
+    int top = 0;                                       // whole levels while they fit
+    for (size_t l = 1; l < h_wide.level_start.size(); l++) if (h_wide.level_start[l] <= wide_top_nodes) top = h_wide.level_start[l];
+    d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = h_wide.depth;
+    d_scene.wprims = d_wprims; d_scene.wmats = d_wmats; d_scene.wmtab = d_wmtab; d_scene.wload_index = d_wload_index; d_scene.wref_slot = d_wref_slot;
 }
 
 void SceneState::setRadiosity(const float* rgb) {
@@ -696,11 +756,16 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // The sweep's cost per segment does not shrink with its living lanes, so its waves want the compaction of every 32nd
     // segment for longer: with the phased kernels' threshold c2 loses 7 %, c3 8 %; at 0.3 x the wave slots a small frame
     // gains (cbox 256^2 +14 %, 362^2 +15 %; 512^2 = 0.5 x the slots -11 % with one launch) and c2's last stretch +0.5 %.
-    const int trav = g.scene.d_scene.traversal;
-    const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED;
+    // the opt-in fast tree: built at the first frame that asks for it; quad scenes keep the exact walk
+    if (g.config.fast_tree && !g.scene.fastReady() && !g.scene.num_quads && g.config.current_integrator == IntegratorType::PathTracing)
+        g.scene.buildFast();
+    DeviceScene scene = g.scene.d_scene;
+    if (g.config.fast_tree && g.scene.fastReady()) scene.traversal = TRAVERSAL_WIDE;
+    const int trav = scene.traversal;
+    const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED || trav == TRAVERSAL_WIDE;
     const long long fit_pct = phased ? 120 : 30;
     const long long wave_slots = g.config.segments_per_launch > 0 || !(phased || trav == TRAVERSAL_SWEEP)
-                                     ? 0 : bounce_resident_waves(g.scene.d_scene, fp, g.config.collect_stats, g.n_cus);
+                                     ? 0 : bounce_resident_waves(scene, fp, g.config.collect_stats, g.n_cus);
     hipStream_t s = r.stream;
     // whatever way this function is left, nothing of this frame is still in flight (an exception thrown between two
     // launches must not let the next frame start on top of the chunk streams' queued work)
@@ -773,7 +838,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
                 for (int k = 0; k < r.n_chunks; k++) active += run[k].finished ? 0 : run[k].bound;
                 const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * fit_pct;
-                launch_bounce(g.scene.d_scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
+                launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
                               fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr,
                               phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream);

@@ -19,6 +19,7 @@
 #include "file_manager.h"
 #include "pbrt_loader.h"
 #include "sensor.h"
+#include "wide_bvh.h"
 
 namespace ptmi {
 
@@ -49,6 +50,7 @@ struct AppConfig {                                   // application_state.h:262-
     bool collect_stats = false;
     float mis_bsdf_fraction = 0.5f;                  // application_state.h:292 / scene.h:217
     IntegratorType current_integrator = IntegratorType::PathTracing;   // application_state.h:283
+    bool fast_tree = false;                          // new: walk the opt-in 8-wide SAH tree instead of the reference's (csrc/wide_bvh.h)
 };
 
 struct SceneState {
@@ -67,6 +69,17 @@ struct SceneState {
     int packed_min_nodes = 8192;
     int packed_top_records = 512;                    // record positions of the packed layout kept in LDS (32 B each: 16 KB,
                                                      // 7 waves per SIMD stay resident); < 2: none
+    // opt-in fast tree for TRAVERSAL_WIDE (csrc/wide_bvh.h), built at the first frame that asks for it (AppConfig::fast_tree)
+    WideBVH h_wide;
+    WideBVHParams wide_params;
+    int wide_top_nodes = 80;                         // whole levels of the fast tree kept in LDS while they fit this many nodes (128 B each)
+    uint4* d_wnodes = nullptr;
+    float* d_wprims = nullptr;
+    float4 *d_wmats = nullptr, *d_wmtab = nullptr;
+    int *d_wload_index = nullptr, *d_wref_slot = nullptr;
+    void buildFast();                                // host build + upload; throws ArgError for scenes with quads
+    void freeFast();
+    bool fastReady() const { return d_wnodes != nullptr; }
     DeviceScene d_scene;
     // guided sampling: per-primitive PrecomputedCDF records (render_config.h:24-31), load order
     std::vector<float> h_precomputed_cdfs;           // n_prims * kCdfDwords: host copy, fetched on demand (precomputedCdfsHost)

@@ -1,0 +1,311 @@
+// wide_bvh.cpp — builder of the opt-in FAST tree: binned-SAH binary tree -> 8-wide collapse -> slot assignment by octant ->
+// breadth-first numbering -> conservative 8-bit quantisation (csrc/wide_bvh.h).  Own code; nothing here has a counterpart in
+// the reference, whose only tree is the midpoint-split binary one of rendering/bvh.h (host/bvh.cpp reproduces that one).
+#include "wide_bvh.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace ptmi {
+
+namespace {
+
+struct Box {
+    float lo[3] = {std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity()};
+    float hi[3] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
+    void grow(const Box& o) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], o.lo[a]); hi[a] = std::max(hi[a], o.hi[a]); } }
+    void grow(const float* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    double area() const {
+        const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x);
+    }
+};
+
+struct Node2 { Box box; int left = -1, right = -1, first = 0, count = 0; };    // count > 0: leaf over order[first .. first + count)
+
+struct Builder2 {
+    const std::vector<Box>& pbox;
+    const std::vector<std::array<float, 3>>& pcen;
+    const WideBVHParams& prm;
+    std::vector<int> order;
+    std::vector<Node2> nodes;
+
+    Builder2(const std::vector<Box>& b, const std::vector<std::array<float, 3>>& c, const WideBVHParams& p) : pbox(b), pcen(c), prm(p) {
+        order.resize(b.size());
+        for (size_t i = 0; i < b.size(); i++) order[i] = (int)i;
+        nodes.reserve(2 * b.size());
+    }
+
+    void build() {
+        struct Job { int node, first, count; };
+        std::vector<Job> jobs;
+        nodes.emplace_back();
+        jobs.push_back({0, 0, (int)order.size()});
+        const int nb = std::max(4, std::min(prm.bins, 64));
+        std::vector<Box> bin_box((size_t)3 * nb), right_acc((size_t)nb);
+        std::vector<int> bin_cnt((size_t)3 * nb);
+        while (!jobs.empty()) {
+            const Job j = jobs.back(); jobs.pop_back();
+            Box bounds, cb;
+            for (int i = j.first; i < j.first + j.count; i++) { bounds.grow(pbox[order[i]]); cb.grow(pcen[order[i]].data()); }
+            nodes[j.node].box = bounds;
+            auto make_leaf = [&] { nodes[j.node].first = j.first; nodes[j.node].count = j.count; };
+            if (j.count == 1) { make_leaf(); continue; }
+            // binned SAH over the three axes in one pass
+            for (auto& b : bin_box) b = Box();
+            std::fill(bin_cnt.begin(), bin_cnt.end(), 0);
+            float k1[3], k0[3];
+            bool usable[3];
+            for (int a = 0; a < 3; a++) {
+                const float ext = cb.hi[a] - cb.lo[a];
+                usable[a] = ext > 0.0f && std::isfinite(ext);
+                k0[a] = cb.lo[a]; k1[a] = usable[a] ? (float)nb * (1.0f - 1e-6f) / ext : 0.0f;
+            }
+            for (int i = j.first; i < j.first + j.count; i++) {
+                const int p = order[i];
+                for (int a = 0; a < 3; a++) {
+                    if (!usable[a]) continue;
+                    const int b = std::min(nb - 1, std::max(0, (int)((pcen[p][a] - k0[a]) * k1[a])));
+                    bin_box[(size_t)a * nb + b].grow(pbox[p]); bin_cnt[(size_t)a * nb + b]++;
+                }
+            }
+            double best = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_split = -1;
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
+                Box acc; int cnt = 0;
+                std::vector<int> rc((size_t)nb);
+                for (int b = nb - 1; b > 0; b--) { acc.grow(bin_box[(size_t)a * nb + b]); cnt += bin_cnt[(size_t)a * nb + b]; right_acc[b] = acc; rc[b] = cnt; }
+                Box l; int lc = 0;
+                for (int b = 0; b + 1 < nb; b++) {
+                    l.grow(bin_box[(size_t)a * nb + b]); lc += bin_cnt[(size_t)a * nb + b];
+                    if (lc == 0 || rc[b + 1] == 0) continue;
+                    const double c = l.area() * lc + right_acc[b + 1].area() * rc[b + 1];
+                    if (c < best) { best = c; best_axis = a; best_split = b + 1; }
+                }
+            }
+            const double area = std::max(bounds.area(), 1e-300);
+            if (j.count <= prm.max_leaf) {
+                const double leaf_cost = (double)prm.c_tri * j.count;
+                const double split_cost = best_axis < 0 ? std::numeric_limits<double>::infinity() : (double)prm.c_trav + (double)prm.c_tri * best / area;
+                if (leaf_cost <= split_cost) { make_leaf(); continue; }
+            }
+            int mid;
+            if (best_axis < 0) {                                  // all centroids coincide: split the index range
+                mid = j.first + j.count / 2;
+            } else {
+                const int a = best_axis;
+                int* lo = order.data() + j.first; int* hi = lo + j.count;
+                int* m = std::partition(lo, hi, [&](int p) { return std::min(nb - 1, std::max(0, (int)((pcen[p][a] - k0[a]) * k1[a]))) < best_split; });
+                mid = (int)(m - order.data());
+                if (mid == j.first || mid == j.first + j.count) mid = j.first + j.count / 2;      // cannot happen (both sides counted non-empty)
+            }
+            const int l = (int)nodes.size(); nodes.emplace_back(); nodes.emplace_back();
+            nodes[j.node].left = l; nodes[j.node].right = l + 1;
+            jobs.push_back({l + 1, mid, j.first + j.count - mid});
+            jobs.push_back({l, j.first, mid - j.first});
+        }
+    }
+};
+
+uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+}  // namespace
+
+void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_in, WideBVH& out) {
+    out.clear();
+    WideBVHParams prm = prm_in;
+    prm.max_leaf = std::max(1, std::min(prm.max_leaf, kWideMaxLeaf));
+    const int n = (int)prims.size();
+    if (n == 0) throw std::invalid_argument("fast tree: scene has no primitives");
+    for (const Primitive& p : prims) if (p.type != PRIM_TRIANGLE) throw std::invalid_argument("fast tree: triangle scenes only");
+
+    // triangle boxes, padded: the kernel's plane distances carry a few ulp of |p - o| + extent, so every box is widened by
+    // 2^-18 of the scene's largest coordinate (cbox: 4e-5) plus the reference's own 1e-6 (bvh.h:108-114) before anything else
+    std::vector<Box> pbox((size_t)n);
+    std::vector<std::array<float, 3>> pcen((size_t)n);
+    float big = 0.0f;
+    for (const Primitive& p : prims) for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
+    if (!(big < 1.0e9f)) throw std::invalid_argument("fast tree: coordinates must stay below 1e9");
+    const float pad = big * (1.0f / 262144.0f) + 1e-6f;
+    for (int i = 0; i < n; i++) {
+        const Primitive& p = prims[i];
+        Box b;
+        for (int k = 0; k < 3; k++) { const float v[3] = {p.v[k].x, p.v[k].y, p.v[k].z}; b.grow(v); }
+        for (int a = 0; a < 3; a++) { pcen[i][a] = 0.5f * (b.lo[a] + b.hi[a]); b.lo[a] -= pad; b.hi[a] += pad; }
+        pbox[i] = b;
+    }
+    Builder2 b2(pbox, pcen, prm);
+    b2.build();
+    const std::vector<Node2>& N = b2.nodes;
+    out.binary_nodes = (int)N.size();
+    for (const Node2& x : N) if (x.count > 0) out.binary_leaves++;
+
+    // ---- collapse: a wide node takes up to 8 descendants of its binary node, always opening the largest inner one next ----
+    struct WNode { int bin; int child[8]; int n_child = 0; int level = 0; };
+    std::vector<WNode> W;
+    W.reserve(N.size() / 4 + 2);
+    W.push_back({0, {}, 0, 1});
+    out.level_start.push_back(0);
+    out.tri_load_index.reserve((size_t)n);
+    std::vector<uint32_t>& nodes = out.nodes;
+    const double root_area = std::max(N[0].box.area(), 1e-300);
+    for (size_t wi = 0; wi < W.size(); wi++) {
+        if (W[wi].level > (int)out.level_start.size()) out.level_start.push_back((int)wi);
+        WNode w = W[wi];
+        int set[8], ns = 0;
+        if (N[w.bin].count > 0) set[ns++] = w.bin;               // a scene of <= max_leaf triangles: the root's only child is a leaf
+        else { set[ns++] = N[w.bin].left; set[ns++] = N[w.bin].right; }
+        while (ns < 8) {
+            int pick = -1; double pa = -1.0;
+            for (int k = 0; k < ns; k++) if (N[set[k]].count == 0) { const double a = N[set[k]].box.area(); if (a > pa) { pa = a; pick = k; } }
+            if (pick < 0) break;
+            const int x = set[pick];
+            set[pick] = N[x].left; set[ns++] = N[x].right;
+        }
+        // ---- slots: child c goes to the slot whose corner direction its centre lies towards (greedy on the best pairs) ----
+        Box nb;
+        for (int k = 0; k < ns; k++) nb.grow(N[set[k]].box);
+        int slot_of[8]; bool slot_used[8] = {}, placed[8] = {};
+        for (int round = 0; round < ns; round++) {
+            double bestc = -std::numeric_limits<double>::infinity(); int bc = -1, bs = -1;
+            for (int k = 0; k < ns; k++) {
+                if (placed[k]) continue;
+                const Box& cbx = N[set[k]].box;
+                for (int s = 0; s < 8; s++) {
+                    if (slot_used[s]) continue;
+                    double c = 0.0;
+                    for (int a = 0; a < 3; a++) {
+                        const double rel = 0.5 * ((double)cbx.lo[a] + cbx.hi[a]) - 0.5 * ((double)nb.lo[a] + nb.hi[a]);
+                        c += ((s >> a) & 1) ? rel : -rel;
+                    }
+                    if (c > bestc) { bestc = c; bc = k; bs = s; }
+                }
+            }
+            placed[bc] = true; slot_used[bs] = true; slot_of[bc] = bs;
+        }
+        int child_in_slot[8];
+        for (int s = 0; s < 8; s++) child_in_slot[s] = -1;
+        for (int k = 0; k < ns; k++) child_in_slot[slot_of[k]] = set[k];
+
+        // ---- record ----
+        const size_t base = nodes.size();
+        nodes.resize(base + kWideNodeDwords, 0u);
+        uint32_t* rec = nodes.data() + base;
+        uint32_t ebias[3];
+        double step[3];
+        for (int a = 0; a < 3; a++) {
+            const double ext = (double)nb.hi[a] - (double)nb.lo[a];
+            int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+            while (std::ldexp(255.0, e) < ext) e++;                 // 255 steps must reach the far side
+            e = std::max(-126, std::min(e, 100));
+            ebias[a] = (uint32_t)(e + 127); step[a] = std::ldexp(1.0, e);
+            rec[a] = float_bits(nb.lo[a]);
+        }
+        uint32_t imask = 0;
+        const uint32_t child_base = (uint32_t)W.size(), tri_base = (uint32_t)out.tri_load_index.size();
+        uint8_t q[6][8];
+        for (int s = 0; s < 8; s++) { for (int pl = 0; pl < 3; pl++) { q[pl][s] = 255; q[3 + pl][s] = 0; } }
+        for (int s = 0; s < 8; s++) {
+            const int c = child_in_slot[s];
+            if (c < 0) continue;
+            const Box& cbx = N[c].box;
+            for (int a = 0; a < 3; a++) {
+                // outward rounding, checked in the arithmetic the kernel's planes stand for: p + q * 2^e as exact reals
+                int lo = (int)std::floor(((double)cbx.lo[a] - (double)nb.lo[a]) / step[a]);
+                int hi = (int)std::ceil(((double)cbx.hi[a] - (double)nb.lo[a]) / step[a]);
+                lo = std::max(0, std::min(lo, 255)); hi = std::max(0, std::min(hi, 255));
+                while (lo > 0 && (double)nb.lo[a] + lo * step[a] > (double)cbx.lo[a]) lo--;
+                while (hi < 255 && (double)nb.lo[a] + hi * step[a] < (double)cbx.hi[a]) hi++;
+                q[a][s] = (uint8_t)lo; q[3 + a][s] = (uint8_t)hi;
+            }
+            out.sah += cbx.area() / root_area;
+            if (N[c].count > 0) {
+                const uint32_t off = (uint32_t)out.tri_load_index.size() - tri_base;
+                for (int i = 0; i < N[c].count; i++) out.tri_load_index.push_back(b2.order[N[c].first + i]);
+                rec[WN_WORD0 + s] = ((1u << N[c].count) - 1u) << off;
+            } else {
+                imask |= 1u << s;
+                rec[WN_WORD0 + s] = 1u << (24 + s);
+                W.push_back({c, {}, 0, w.level + 1});
+            }
+        }
+        rec[3] = ebias[0] | (ebias[1] << 8) | (ebias[2] << 16) | (imask << 24);
+        rec[4] = child_base; rec[5] = tri_base;
+        for (int pl = 0; pl < 6; pl++) {
+            rec[WN_PLANES0 + 2 * pl] = (uint32_t)q[pl][0] | ((uint32_t)q[pl][1] << 8) | ((uint32_t)q[pl][2] << 16) | ((uint32_t)q[pl][3] << 24);
+            rec[WN_PLANES0 + 2 * pl + 1] = (uint32_t)q[pl][4] | ((uint32_t)q[pl][5] << 8) | ((uint32_t)q[pl][6] << 16) | ((uint32_t)q[pl][7] << 24);
+        }
+        out.depth = std::max(out.depth, w.level);
+    }
+    out.n_nodes = (int)W.size();
+    out.level_start.push_back(out.n_nodes);
+    if ((int)out.tri_load_index.size() != n) throw std::logic_error("fast tree: triangle count mismatch");
+}
+
+namespace {
+// Triangle::intersect (triangle.h:64-96) with precomputed edges, accept test as pt_device.h: mt_accept states it
+bool mt_host(const Primitive& p, f3 o, f3 d, float t_lo, float& t) {
+    const f3 edge1 = p.v[1] - p.v[0], edge2 = p.v[2] - p.v[0];
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    if (std::fabs(a) < 1e-8f) return false;
+    const float f = 1.0f / a;
+    const f3 s = o - p.v[0];
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = f * dot(edge2, q);
+    return t >= t_lo;
+}
+}  // namespace
+
+int wideIntersectHost(const WideBVH& bvh, const std::vector<Primitive>& prims, const std::vector<int>& ref_slot, f3 o, f3 d,
+                      float t_min, float t_max, float& t_hit, WideWalkCounters* cn) {
+    const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
+    const uint32_t octinv = wide_octinv(inv);
+    const float eps_up = wb_as_float(float_bits(1e-8f) + 1u);
+    const float t_lo = t_min > 1e-8f ? t_min : eps_up;
+    float closest = t_max;
+    int hit = -1;
+    struct Group { uint32_t base, bits; };
+    std::vector<Group> stack;
+    Group g{0u, (1u << 8) | (1u << octinv)};                    // the root: slot 0 of a virtual parent with imask 1
+    const uint4* recs = reinterpret_cast<const uint4*>(bvh.nodes.data());
+    while (true) {
+        if ((g.bits & 0xffu) == 0u) {
+            if (stack.empty()) break;
+            g = stack.back(); stack.pop_back();
+        }
+        const uint32_t hits = g.bits & 0xffu;
+        const int bit = 31 - __builtin_clz(hits);
+        g.bits ^= 1u << bit;
+        const uint32_t slot = (uint32_t)bit ^ octinv, imask = g.bits >> 8;
+        const uint32_t ni = g.base + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+        if (g.bits & 0xffu) stack.push_back(g);
+        if (cn) { cn->node_visits++; cn->max_stack = std::max<uint64_t>(cn->max_stack, stack.size()); }
+        const uint4* q = recs + (size_t)ni * (kWideNodeDwords / 4);
+        const WideStep st = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], o, inv, octinv, t_min, closest);
+        uint32_t tris = st.tris;
+        while (tris) {
+            const int k = (int)st.tri_base + __builtin_ctz(tris);
+            tris &= tris - 1u;
+            if (cn) cn->prim_tests++;
+            const int li = bvh.tri_load_index[(size_t)k];
+            float t;
+            if (!mt_host(prims[(size_t)li], o, d, t_lo, t)) continue;
+            if (t < closest || (t == closest && hit >= 0 && ref_slot[(size_t)li] < ref_slot[(size_t)hit])) { closest = t; hit = li; }
+        }
+        g = Group{st.child_base, (st.imask << 8) | st.inner};
+    }
+    t_hit = closest;
+    return hit;
+}
+
+}  // namespace ptmi

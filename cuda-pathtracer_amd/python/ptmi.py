@@ -28,6 +28,7 @@ EXPORTS = [
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
     "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
+    "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect",
 ]
 
 
@@ -39,7 +40,7 @@ class Camera(C.Structure):
 class Config(C.Structure):
     _fields_ = [("spp", C.c_int), ("max_depth", C.c_int), ("sampling_mode", C.c_int), ("seed_base", C.c_uint64),
                 ("segments_per_launch", C.c_int), ("collect_stats", C.c_int), ("wave_tiles", C.c_int), ("streams", C.c_int), ("mis_bsdf_fraction", C.c_float), ("integrator", C.c_int),
-                ("download_image", C.c_int)]
+                ("download_image", C.c_int), ("fast_tree", C.c_int)]
 
 
 class Tiling(C.Structure):
@@ -142,6 +143,10 @@ def lib():
         L.ptmi_debug_set_packed_min_nodes.argtypes = [vp, C.c_int, ip]
         L.ptmi_debug_set_packed_top.argtypes = [vp, C.c_int, ip, ip]
         L.ptmi_debug_place_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.ptmi_debug_set_fast_tree.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, ip]
+        L.ptmi_debug_intersect_fast.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
+        L.ptmi_host_fast_tree_build.argtypes = [vp, C.c_int, C.c_float, C.c_float, ip, ip, C.POINTER(C.c_double)]
+        L.ptmi_host_fast_tree_intersect.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -199,6 +204,21 @@ class HostScene:
         _check(lib().ptmi_host_scene_get_bvh(self.h, bmin.ctypes.data, bmax.ctypes.data, left.ctypes.data, right.ctypes.data,
                                              count.ctypes.data, idx.ctypes.data))
         return dict(bmin=bmin, bmax=bmax, left=left, right=right, count=count, indices=idx)
+
+
+    # --- the opt-in fast tree (csrc/wide_bvh.h), host halves ---
+    def fast_tree_build(self, max_leaf=3, c_trav=1.0, c_tri=1.0):
+        n = C.c_int(); d = C.c_int(); sah = C.c_double()
+        _check(lib().ptmi_host_fast_tree_build(self.h, int(max_leaf), float(c_trav), float(c_tri), C.byref(n), C.byref(d), C.byref(sah)))
+        return dict(n_nodes=n.value, depth=d.value, sah=sah.value)
+
+    def fast_tree_intersect(self, o, d, t_min=1e-4, t_max=3.4028234663852886e38):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        prim = np.zeros(n, np.int32); t = np.zeros(n, np.float32); counts = np.zeros(3, np.uint64)
+        _check(lib().ptmi_host_fast_tree_intersect(self.h, n, o.ctypes.data, d.ctypes.data, t_min, t_max, prim.ctypes.data, t.ctypes.data,
+                                                   counts.ctypes.data))
+        return dict(prim=prim, t=t, node_visits=int(counts[0]), prim_tests=int(counts[1]), max_stack=int(counts[2]))
 
 
 def host_camera_frame(cam, width, height):
@@ -352,7 +372,7 @@ class Renderer:
         self._ck(self.L.ptmi_set_camera(self.h, C.byref(cam)))
 
     def set_config(self, spp=None, max_depth=None, seed_base=None, segments_per_launch=None, collect_stats=None, wave_tiles=None, streams=None,
-                   sampling_mode=None, mis_bsdf_fraction=None, integrator=None, download_image=None):
+                   sampling_mode=None, mis_bsdf_fraction=None, integrator=None, download_image=None, fast_tree=None):
         c = self.config
         if spp is not None: c.spp = int(spp)
         if max_depth is not None: c.max_depth = int(max_depth)
@@ -365,6 +385,7 @@ class Renderer:
         if mis_bsdf_fraction is not None: c.mis_bsdf_fraction = float(mis_bsdf_fraction)
         if integrator is not None: c.integrator = int(integrator)
         if download_image is not None: c.download_image = int(bool(download_image))
+        if fast_tree is not None: c.fast_tree = int(bool(fast_tree))
         self._ck(self.L.ptmi_set_config(self.h, C.byref(c)))
 
     def camera_frame(self):
@@ -505,6 +526,19 @@ class Renderer:
         self._ck(self.L.ptmi_debug_intersect(self.h, n, o.ctypes.data, d.ctypes.data, t_min, t_max, hit.ctypes.data,
                                              prim.ctypes.data, t.ctypes.data, p.ctypes.data, nr.ctypes.data))
         return dict(hit=hit, prim=prim, t=t, p=p, n=nr)
+
+    def debug_set_fast_tree(self, max_leaf=3, c_trav=1.0, c_tri=1.0, top_nodes=80):
+        n = C.c_int(); d = C.c_int(); t = C.c_int()
+        self._ck(self.L.ptmi_debug_set_fast_tree(self.h, int(max_leaf), float(c_trav), float(c_tri), int(top_nodes), C.byref(n), C.byref(d), C.byref(t)))
+        return dict(n_nodes=n.value, depth=d.value, n_top=t.value)
+
+    def debug_intersect_fast(self, o, d, t_min=1e-4, t_max=3.4028234663852886e38):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.int32); prim = np.zeros(n, np.int32); t = np.zeros(n, np.float32); counts = np.zeros(2, np.uint64)
+        self._ck(self.L.ptmi_debug_intersect_fast(self.h, n, o.ctypes.data, d.ctypes.data, t_min, t_max, hit.ctypes.data,
+                                                  prim.ctypes.data, t.ctypes.data, counts.ctypes.data))
+        return dict(hit=hit, prim=prim, t=t, node_visits=int(counts[0]), prim_tests=int(counts[1]))
 
     def debug_rng(self, seed_base, pixels, count):
         pixels = np.ascontiguousarray(pixels, np.int32)

@@ -88,6 +88,13 @@ typedef struct {
     int      download_image;      /* 1: ptmi_render_frame ends like renderFrame() does, with the D2H of the 8-bit image into the
                                    * ctx's pinned host image (RenderState::h_image, application.h:211) - read it through
                                    * ptmi_host_image.  0 (default): results stay on the device until asked for */
+    int      fast_tree;           /* 0 (default): walk the reference's own tree (rendering/bvh.h:156-218) - frames bit-identical
+                                   * to the reference's.  1: opt-in FAST tree for triangle scenes (last bullet): an
+                                   * 8-wide binned-SAH tree with conservatively quantised boxes, built at the first frame that
+                                   * asks for it.  Triangles, hit arithmetic, RNG draws and shading are untouched; a ray's hit can
+                                   * differ only where two triangles are hit at exactly the same t or where the reference's own
+                                   * slab test drops a grazing box (cuda-pathtracer_amd/csrc/wide_bvh.h).  Scenes with quads
+                                   * keep the exact walk */
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).
@@ -312,6 +319,20 @@ int ptmi_debug_set_packed_top(ptmi_ctx*, int top_records, int* n_top, int* top_d
 /* Scene::intersect (scene.h:39-110) for n rays given as-is (no normalisation). out_*: n each; p/nrm 3n. */
 int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
                          int* hit, int* prim, float* t, float* p, float* nrm);
+/* The opt-in fast tree (ptmi_config.fast_tree; cuda-pathtracer_amd/csrc/wide_bvh.h).  Builder knobs: max_leaf 1..3 triangles per
+ * leaf child (default 3), c_trav / c_tri = SAH cost of a box level / a triangle test (1, 1), top_nodes = whole levels kept in
+ * LDS while they fit this many 128-byte nodes (80).  Rebuilds the loaded scene's fast tree at once (triangle scenes only) and
+ * applies to later loads; any out pointer may be NULL. */
+int ptmi_debug_set_fast_tree(ptmi_ctx*, int max_leaf, float c_trav, float c_tri, int top_nodes, int* n_nodes, int* depth, int* n_top);
+/* Closest hit through the fast tree for n rays as given (the walk of ptmi_bounce_wide).  prim: load-order index or -1;
+ * counts (may be NULL): [0] node visits, [1] triangle tests, summed over the rays. */
+int ptmi_debug_intersect_fast(ptmi_ctx*, int n, const float* o, const float* d, float t_min, float t_max,
+                              int* hit, int* prim, float* t, uint64_t* counts);
+/* Host-only halves of the same: build the fast tree of a host scene, and walk it on the CPU decision for decision as the
+ * kernel does (tests of the builder without a GPU). */
+int ptmi_host_fast_tree_build(ptmi_host_scene*, int max_leaf, float c_trav, float c_tri, int* n_nodes, int* depth, double* sah);
+int ptmi_host_fast_tree_intersect(const ptmi_host_scene*, int n, const float* o, const float* d, float t_min, float t_max,
+                                  int* prim, float* t, uint64_t* counts /* [0] node visits [1] triangle tests [2] deepest stack */);
 /* render_init + curand_uniform: first `count` uniforms of pixel stream (seed_base+pixel, subsequence pixel). */
 int ptmi_debug_rng(ptmi_ctx*, uint64_t seed_base, int n_pixels, const int* pixels, int count, float* out /* n_pixels*count */);
 /* Compares the kernels' short reciprocal (1 v_rcp + 4 fma, used for Moller-Trumbore's 1/a) with the IEEE quotient for

@@ -1,0 +1,249 @@
+"""The opt-in FAST tree (ptmi_config.fast_tree; cuda-pathtracer_amd/csrc/wide_bvh.h).
+
+SURVEY 7 (last bullet): "may offer an SAH/wide tree for speed runs (results identical except exact-tie cases, which must be
+reported)"; BASELINE's bar is pixel RMSE < 1e-4.  The fast walk tests the reference's triangles with the reference's
+arithmetic and only chooses other boxes on the way, so these tests first ask for MORE than the bar - the same triangle and
+the same t for every ray, the same frame bit for bit - report what differs (the count is printed and, for the frames,
+bounded), and assert the bar itself (RMSE < 1e-4) on the rows of BASELINE configs[4] that the exact test renders.
+
+CPU part (no GPU): the builder and the host-side walk, which takes the kernel's decisions one for one, against the oracle's
+Scene::intersect.  GPU part: the kernel's walk against the host walk (same hits, same visit counts), frames against the
+oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ptmi
+import ptmi_scenes
+from oracle_binding import OracleScene, SCENES, default_camera
+
+F = np.float32
+FLT_MAX = 3.4028234663852886e38
+
+
+def bits(a):
+    return np.ascontiguousarray(a, F).view(np.uint32)
+
+
+def tess(cu, cv):
+    base = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj")).prims()
+    sc = ptmi_scenes.tessellated_cornell(base, cu, cv, seed=1)
+    return (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
+
+
+def soup(n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-2, 2, (n, 1, 3)).astype(F)
+    v = np.zeros((n, 4, 3), F); v[:, :3] = c + rng.uniform(-0.3, 0.3, (n, 3, 3)).astype(F)
+    nr = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]); nr /= np.maximum(np.linalg.norm(nr, axis=1, keepdims=True), 1e-20)
+    return (np.zeros(n, np.int32), v, nr.astype(F), rng.uniform(0.2, 0.9, (n, 3)).astype(F), (rng.uniform(0, 1, (n, 3)) > 0.9).astype(F) * 5)
+
+
+def rays(n, seed):
+    """half from the default camera's side into the box, half from inside it; plus axis-parallel and grazing ones"""
+    rng = np.random.default_rng(seed)
+    o = np.concatenate([np.tile(np.array([[0.0, 2.5, 8.5]], F), (n // 2, 1)), rng.uniform([-2.5, 0.2, -5], [2.0, 5, -0.5], (n - n // 2, 3)).astype(F)])
+    d = rng.normal(size=(n, 3)).astype(F); d[: n // 2, 2] = -np.abs(d[: n // 2, 2]) - 2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n - n // 2
+    ax = np.zeros((min(60, k), 3), F)
+    for i in range(len(ax)):
+        ax[i, i % 3] = 1.0 if (i // 3) % 2 else -1.0                     # exactly axis-parallel: 1/0 slopes
+    d[n // 2: n // 2 + len(ax)] = ax
+    return o, d.astype(F)
+
+
+def oracle_hits(o, org, d, t_min=1e-4, t_max=FLT_MAX):
+    hs = [o.intersect(org[i], d[i], t_min, t_max) for i in range(len(org))]
+    hit = np.array([h.hit for h in hs], bool)
+    return (np.where(hit, np.array([h.prim for h in hs]), -1), np.where(hit, np.array([h.t for h in hs], F), F(0)),
+            float(np.mean([h.node_visits for h in hs])), float(np.mean([h.prim_tests for h in hs])))
+
+
+SCENE_CASES = [("cbox", None), ("cbox_sub3", None), ("tess32x16", None), ("soup3000", None), ("soup2", None)]
+
+
+def scene_arrays(name):
+    if name == "cbox":
+        p = ptmi.HostScene.load(os.path.join(SCENES, "cbox.obj")).prims()
+    elif name == "cbox_sub3":
+        p = ptmi.HostScene.load(os.path.join(SCENES, "cbox.obj"), 3, False).prims()
+    elif name == "tess32x16":
+        return tess(32, 16)
+    elif name == "soup3000":
+        return soup(3000, 5)
+    elif name == "soup2":
+        return soup(2, 6)
+    return (p["type"], p["verts"], p["normal"], p["bsdf"], p["Le"])
+
+
+@pytest.mark.parametrize("name", [c[0] for c in SCENE_CASES])
+@pytest.mark.parametrize("max_leaf", [1, 3])
+def test_host_walk_finds_the_oracles_hits(name, max_leaf):
+    """Same triangle and same t (bit for bit) as Scene::intersect for every ray, incl. [t_min, t_max] windows."""
+    arrs = scene_arrays(name)
+    hs = ptmi.HostScene.from_arrays(*arrs)
+    info = hs.fast_tree_build(max_leaf)
+    assert info["n_nodes"] >= 1 and 1 <= info["depth"] <= 48
+    o = OracleScene.from_arrays(*arrs)
+    org, d = rays(3000, 11)
+    for t_min, t_max in ((1e-4, FLT_MAX), (0.5, 9.0)):
+        prim, t, nodes_exact, tests_exact = oracle_hits(o, org, d, t_min, t_max)
+        r = hs.fast_tree_intersect(org, d, t_min, t_max)
+        bad = int((prim != r["prim"]).sum() + (bits(t) != bits(r["t"])).sum())
+        print(f"{name} max_leaf {max_leaf} [{t_min}, {t_max:.3g}]: {int((prim >= 0).sum())} hits, {bad} differ; node visits per ray "
+              f"{r['node_visits'] / len(org):.2f} (exact walk {nodes_exact:.2f}), triangle tests {r['prim_tests'] / len(org):.2f} ({tests_exact:.2f})")
+        assert bad == 0
+        assert r["max_stack"] < info["depth"]
+
+
+def test_fast_tree_is_for_triangle_scenes():
+    hs = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj"))
+    with pytest.raises(ptmi.PtmiError) as e:
+        hs.fast_tree_build()
+    assert "triangle" in str(e.value)
+    with pytest.raises(ptmi.PtmiError):
+        hs.fast_tree_intersect(np.zeros((1, 3), F), np.ones((1, 3), F))      # nothing built
+
+
+def test_coplanar_ties_keep_the_references_choice():
+    """Rays aimed at shared edges and vertices of coplanar triangles: both are hit at the same t, the reference keeps the one it
+    visits first (scene.h:89-90); the fast walk must name the same triangle (cbox.obj's left wall halves carry different vn)."""
+    p = ptmi.HostScene.load(os.path.join(SCENES, "cbox.obj"), 2, False).prims()
+    arrs = (p["type"], p["verts"], p["normal"], p["bsdf"], p["Le"])
+    hs = ptmi.HostScene.from_arrays(*arrs); hs.fast_tree_build(3)
+    o = OracleScene.from_arrays(*arrs)
+    v = p["verts"][:, :3]
+    targets = np.concatenate([v.reshape(-1, 3), 0.5 * (v[:, 0] + v[:, 1]), 0.5 * (v[:, 1] + v[:, 2]), 0.5 * (v[:, 0] + v[:, 2])]).astype(F)
+    org = np.tile(np.array([[0.1, 2.6, 3.0]], F), (len(targets), 1))
+    d = targets - org; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+    prim, t, _, _ = oracle_hits(o, org, d)
+    r = hs.fast_tree_intersect(org, d)
+    ties = 0
+    for i in range(len(org)):                       # how many of these rays really are ties: a second triangle at the same t
+        if prim[i] >= 0:
+            h2 = o.intersect(org[i], d[i], 1e-4, FLT_MAX, use_bvh=False)
+            ties += int(h2.hit and h2.prim != prim[i] and F(h2.t) == t[i])
+    bad = int((prim != r["prim"]).sum() + (bits(t) != bits(r["t"])).sum())
+    print(f"{len(org)} edge/vertex rays, {bad} differ from the reference's choice")
+    assert bad == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def R():
+    r = ptmi.Renderer(0)
+    yield r
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cbox", "cbox_sub3", "tess32x16", "soup3000"])
+def test_gpu_walk_equals_host_walk(R, name):
+    """ptmi_debug_intersect_fast (the kernel's walk) against the host walk: same hits, same t, and the same number of node
+    visits and triangle tests in total - the two take the same decisions - and both equal the oracle's hits."""
+    arrs = scene_arrays(name)
+    R.load_scene_arrays(*arrs)
+    info = R.debug_set_fast_tree(3)
+    hs = ptmi.HostScene.from_arrays(*arrs); hinfo = hs.fast_tree_build(3)
+    assert (info["n_nodes"], info["depth"]) == (hinfo["n_nodes"], hinfo["depth"])
+    org, d = rays(20000, 3)
+    g = R.debug_intersect_fast(org, d)
+    h = hs.fast_tree_intersect(org, d)
+    gp = np.where(g["hit"] > 0, g["prim"], -1)
+    assert (gp == h["prim"]).all() and (bits(g["t"]) == bits(h["t"])).all()
+    assert (g["node_visits"], g["prim_tests"]) == (h["node_visits"], h["prim_tests"])
+    e = R.debug_intersect(org, d)                    # the exact walk on the GPU (already checked against the oracle elsewhere)
+    assert (np.where(e["hit"] > 0, e["prim"], -1) == gp).all() and (bits(np.where(e["hit"] > 0, e["t"], 0)) == bits(g["t"])).all()
+
+
+def frame_diff(a, b):
+    nd = int((bits(a) != bits(b)).any(axis=-1).sum())
+    rmse = float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+    return nd, rmse, float(np.abs(a.astype(np.float64) - b).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,sub,W,H,spp,depth", [("cbox.obj", 0, 160, 120, 16, 8), ("cbox.obj", 3, 128, 128, 8, 5)])
+def test_fast_frames_of_small_scenes(R, name, sub, W, H, spp, depth):
+    """Whole frames through ptmi_bounce_wide against the oracle: reported, and here required to be identical (no tie or grazing
+    case is expected to reach a pixel of these views); every segments-per-launch setting and a frame batch give the same."""
+    path = os.path.join(SCENES, name)
+    R.load_scene(path, sub, False); R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, fast_tree=True, segments_per_launch=0, collect_stats=True)
+    st = R.render_frame()
+    rgb, rad = R.read_image()
+    orgb, orad, ost = OracleScene.load(path, sub, False).render(default_camera(), W, H, spp, max_depth=depth)
+    nd, rmse, mx = frame_diff(rad, orad)
+    print(f"{name} sub {sub} {W}x{H}x{spp}: {nd} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}; node visits per ray "
+          f"{st.node_visits / st.rays:.2f} (exact {ost.node_visits / ost.rays:.2f}), triangle tests {st.prim_tests / st.rays:.2f} ({ost.prim_tests / ost.rays:.2f})")
+    assert rmse < 1e-4 and nd == 0 and (rgb == orgb).all()
+    assert (st.rays, st.hits) == (ost.rays, ost.hits)
+    R.set_config(collect_stats=False)
+    for seg in (1, 5):
+        R.update_resolution(W, H); R.set_config(segments_per_launch=seg); R.render_frame()
+        assert (bits(R.read_image(rgb8=False)[1]) == bits(rad)).all(), seg
+    R.update_resolution(W, H); R.set_config(segments_per_launch=0)
+    R.render_frames(2)
+    R.select_frame(0)
+    assert (bits(R.read_image(rgb8=False)[1]) == bits(rad)).all()
+    R.set_config(fast_tree=False)
+
+
+@pytest.mark.gpu
+def test_fast_tree_on_a_quad_scene_keeps_the_exact_walk(R):
+    path = os.path.join(SCENES, "cbox_quads.obj")
+    R.load_scene(path); R.update_resolution(64, 64)
+    R.set_config(spp=4, max_depth=5, fast_tree=True)
+    R.render_frame()
+    _, rad = R.read_image()
+    _, orad, _ = OracleScene.load(path).render(default_camera(), 64, 64, 4, max_depth=5)
+    assert (bits(rad) == bits(orad)).all()
+    R.set_config(fast_tree=False)
+
+
+@pytest.mark.gpu
+def test_fast_tree_config5_rows(R):
+    """BASELINE configs[4] (1,048,576 triangles, 2048^2, depth 8): the rows the exact test renders (tests/test_gpu_fullsize.py),
+    through the fast tree: #pixels that differ from the oracle, max abs and RMSE are reported; the bar is RMSE < 1e-4."""
+    W = H = 2048; depth = 8
+    args = tess(256, 128)
+    R.load_scene_arrays(*args)
+    o = OracleScene.from_arrays(*args)
+    info = R.debug_set_fast_tree(3)
+    print("fast tree:", info)
+    # one GPU's share (rank 3 of 8), one row at 256 spp against the oracle
+    R.set_config(spp=256, max_depth=depth, segments_per_launch=0, collect_stats=True, fast_tree=True)
+    R.update_resolution(W, H, n_ranks=8, rank=3, row_block=8)
+    st = R.render_frame()
+    rows = R.local_rows()
+    _, rad = R.read_image()
+    y = int(rows[100])
+    _, orad, ost = o.render(default_camera(), W, H, 256, max_depth=depth, y0=y, y1=y + 1)
+    nd, rmse, mx = frame_diff(rad[100], orad[y])
+    print(f"config 5, row {y} at 256 spp: {nd} of {W} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}; "
+          f"node visits per ray {st.node_visits / st.rays:.2f}, triangle tests per ray {st.prim_tests / st.rays:.2f}, "
+          f"LDS-served visits {st.top_node_visits / st.node_visits:.3f}")
+    assert rmse < 1e-4
+    assert st.node_visits / st.rays <= 30.0                      # node fetches per ray <= 30 (exact walk: 72.5)
+    # whole frame at 16 spp: rows 1000..1003 against the oracle, tile union == unsharded frame
+    R.set_config(spp=16, collect_stats=False)
+    R.update_resolution(W, H); R.render_frame()
+    _, full = R.read_image(rgb8=False)
+    _, orad, _ = o.render(default_camera(), W, H, 16, max_depth=depth, y0=1000, y1=1004)
+    nd, rmse, mx = frame_diff(full[1000:1004], orad[1000:1004])
+    print(f"config 5, rows 1000:1004 at 16 spp: {nd} of {4 * W} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}")
+    assert rmse < 1e-4
+    R.update_resolution(W, H, n_ranks=8, rank=5, row_block=8); R.render_frame()
+    assert (bits(R.read_image(rgb8=False)[1]) == bits(full[R.local_rows()])).all()
+    # and against the exact walk on the GPU, whole frame: how many pixels the two trees disagree on
+    R.set_config(fast_tree=False)
+    R.update_resolution(W, H); R.render_frame()
+    _, exact = R.read_image(rgb8=False)
+    nd, rmse, mx = frame_diff(full, exact)
+    print(f"config 5, whole 2048^2 frame at 16 spp, fast tree vs exact walk: {nd} of {W * H} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}")
+    assert rmse < 1e-4
