@@ -11,8 +11,11 @@
 // ROCm's own <hip/amd_detail/host_defines.h> (shipped in this image) defines
 // as empty for a plain g++ host compile.  No stand-in headers are written.
 //
-// What is NOT compiled (needs <cuda_runtime.h>/<curand_kernel.h>, absent here):
-// rendering/integrator.h (via grid.h), utils/file_manager.h, application_state.h.
+// utils/file_manager.h (loadOBJ / loadMTL) is compiled too, in ref_obj_harness.cpp: it needs <cuda_runtime.h>, and
+// NVIDIA's genuine header ships in this image's Triton wheel (oracle/Makefile finds it).
+// What is NOT compilable here: rendering/grid.h (hence integrator.h) and rendering/form_factors.h include
+// <curand_kernel.h> (closed NVIDIA library, nowhere in the image); rendering/grid_filter.h launches kernels with
+// <<< >>> from host wrappers (no g++ can parse it); application_state.h includes GL/glew.h and GLFW.
 // Those are restated in ptmi_oracle.c only.
 #include <hip/amd_detail/host_defines.h>
 

@@ -401,3 +401,35 @@ def ref_pbrt_load(path):
     L.ref_pbrt_get(h, t.ctypes.data, v.ctypes.data, nr.ctypes.data, b.ctypes.data, le.ctypes.data)
     L.ref_pbrt_free(h)
     return dict(type=t, verts=v, normal=nr, bsdf=b, Le=le)
+
+
+# ---- the reference's OBJ/MTL loader, compiled (oracle/_ref/libptmi_ref_obj.so; needs NVIDIA's own cuda_runtime.h at build time) ----
+REF_OBJ_SO = os.path.join(os.path.dirname(REF_SO), "libptmi_ref_obj.so")
+_ref_obj = None
+
+
+def ref_obj_available():
+    return os.path.exists(REF_OBJ_SO)
+
+
+def ref_obj_load(path):
+    """loadOBJ (+ loadMTL) of the reference on `path`: dict(type, verts, normal, bsdf, Le, warnings) or None where it returns false."""
+    global _ref_obj
+    if _ref_obj is None:
+        L = C.CDLL(REF_OBJ_SO)
+        L.ref_obj_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.ref_obj_warning_count.argtypes = [C.c_void_p]
+        L.ref_obj_get.argtypes = [C.c_void_p] * 6; L.ref_obj_free.argtypes = [C.c_void_p]; L.ref_obj_free.restype = None
+        _ref_obj = L
+    L = _ref_obj
+    n = C.c_int(); h = C.c_void_p()
+    ok = L.ref_obj_load(os.fsencode(path), C.byref(n), C.byref(h))
+    out = None
+    if ok:
+        t = np.zeros(n.value, np.int32); v = np.zeros((n.value, 4, 3), np.float32)
+        nr = np.zeros((n.value, 3), np.float32); b = np.zeros((n.value, 3), np.float32); le = np.zeros((n.value, 3), np.float32)
+        if n.value:
+            L.ref_obj_get(h, t.ctypes.data, v.ctypes.data, nr.ctypes.data, b.ctypes.data, le.ctypes.data)
+        out = dict(type=t, verts=v, normal=nr, bsdf=b, Le=le, warnings=L.ref_obj_warning_count(h))
+    L.ref_obj_free(h)
+    return out

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import ptmi
-from oracle_binding import OracleScene, SCENES, Camera as OCamera, camera_frame, default_camera
+from oracle_binding import OracleScene, SCENES, Camera as OCamera, camera_frame, default_camera, ref_obj_available, ref_obj_load
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = np.float32
@@ -187,7 +187,7 @@ def test_loader_differential_fuzz(tmp_path):
     from file_manager.h:39-273 - must agree on accept/reject and, where accepted, on every bit."""
     rng = np.random.default_rng(2024)
     num = lambda: rng.choice([f"{rng.uniform(-4, 4):.4f}", f"{rng.integers(-3, 4)}", f"{rng.uniform(-1, 1):.3e}", "0", "-0.0", "1e-3", ".5", "+2"])
-    agree_ok = agree_fail = 0
+    agree_ok = agree_fail = ref_ok = ref_fail = 0
     for case in range(300):
         nv = int(rng.integers(0, 9)) if rng.random() < 0.15 else int(rng.integers(3, 10)); nn = int(rng.integers(0, 4))
         mtl_lines = []
@@ -219,6 +219,29 @@ def test_loader_differential_fuzz(tmp_path):
         (d / "m.mtl").write_text("\n".join(mtl_lines) + "\n")
         (d / "s.obj").write_text("\n".join(lines) + ("\n" if rng.random() < 0.9 else ""))
         sub = int(rng.integers(0, 3)); conv = bool(rng.random() < 0.5)
+        # a Kd / Ke line with fewer than three numbers makes the reference read uninitialised floats (file_manager.h:62-69:
+        # `float r, g, b; iss >> r >> g >> b;` unchecked - in the compiled reference the previous line's values show through);
+        # both restatements store 0 for what is missing, and such files are left out of the comparison with the compiled reference
+        short_colour = any(l.split()[:1] in (["Kd"], ["Ke"]) and len(l.split()) < 4 for l in mtl_lines)
+        if ref_obj_available() and not short_colour:
+            # the reference's own loadOBJ / loadMTL (utils/file_manager.h:39-79, 93-273, compiled into oracle/_ref): the product's
+            # loader and the oracle's must take its decision and reproduce every bit of what it returns
+            want = ref_obj_load(str(d / "s.obj"))
+            got = []
+            for load in (ptmi.HostScene.load, OracleScene.load):
+                try:
+                    got.append(load(str(d / "s.obj"), 0, False).prims())
+                except Exception:
+                    got.append(None)
+            for g in got:
+                assert (g is None) == (want is None or len(want["type"]) == 0), (case, lines)
+                if g is not None:
+                    assert (g["type"] == want["type"]).all(), case
+                    tri = g["type"] == 0
+                    assert (bits(g["verts"][tri][:, :3]) == bits(want["verts"][tri][:, :3])).all() and (bits(g["verts"][~tri]) == bits(want["verts"][~tri])).all(), case
+                    for k in ("normal", "bsdf", "Le"):
+                        assert (bits(g[k]) == bits(want[k])).all(), (case, k)
+            ref_ok += got[0] is not None; ref_fail += got[0] is None
         try:
             h = ptmi.HostScene.load(str(d / "s.obj"), sub, conv)
         except ptmi.PtmiError:
@@ -243,4 +266,6 @@ def test_loader_differential_fuzz(tmp_path):
         assert len(hb["left"]) == len(ob["left"]) and (hb["indices"] == ob["indices"]).all() and (hb["count"] == ob["count"]).all(), case
         assert (bits(hb["bmin"]) == bits(ob["bmin"])).all() and (bits(hb["bmax"]) == bits(ob["bmax"])).all(), case
     assert agree_ok > 60 and agree_fail > 20, (agree_ok, agree_fail)
-    print(f"loader fuzz: {agree_ok} accepted, {agree_fail} rejected, all agreeing")
+    print(f"loader fuzz: {agree_ok} accepted, {agree_fail} rejected, all agreeing; against the compiled reference loader: {ref_ok} accepted, {ref_fail} rejected")
+    if ref_obj_available():
+        assert ref_ok > 60 and ref_fail > 20

@@ -3,11 +3,13 @@
 BVHBuilder output, Scene::intersect (BVH and linear), Sensor, unit_vector,
 constructor normals.  Skipped where oracle/_ref was never built.
 """
+import os
+
 import numpy as np
 import pytest
 
 from oracle_binding import (OracleScene, RefScene, SCENES, Camera, camera_frame, camera_ray, default_camera,
-                            ref_available, ref_camera, ref_lib)
+                            ref_available, ref_camera, ref_lib, ref_obj_available, ref_obj_load)
 
 pytestmark = pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 F = np.float32
@@ -224,3 +226,22 @@ def test_render_config_layout_and_constants():
     oc = np.zeros(6, np.float64); oracle_lib().po_grid_constants(oc.ctypes.data)
     assert (rc.view(np.uint64) == oc.view(np.uint64)).all(), (rc, oc)
     assert rc[4] == np.pi                                                        # M_PI: the double constant, not math_utils.h's float
+
+
+@pytest.mark.skipif(not ref_obj_available(), reason="oracle/_ref/libptmi_ref_obj.so not built (needs /root/reference and NVIDIA's cuda_runtime.h)")
+@pytest.mark.parametrize("name,n_tris,n_quads,warnings", [("cbox.obj", 32, 0, 0), ("cbox_quads.obj", 0, 16, 20)])
+def test_obj_loader_against_the_compiled_reference_loader(name, n_tris, n_quads, warnings):
+    """loadOBJ + loadMTL of the reference itself (utils/file_manager.h:39-79, 93-273, compiled unmodified against
+    NVIDIA's own cuda_runtime.h) on the two Cornell files: the oracle's C loader and the product's C++ loader return its
+    primitives bit for bit - type, vertices, stored normal (first vn or geometric), Kd, Ke - incl. the 20 "malformed face
+    vertex token" warnings of cbox_quads.obj:100-112 (trailing '# Top' comments), which must not change the result."""
+    import ptmi
+    path = os.path.join(SCENES, name)
+    want = ref_obj_load(path)
+    assert want is not None and ((want["type"] == 0).sum(), (want["type"] == 1).sum(), want["warnings"]) == (n_tris, n_quads, warnings)
+    for got in (OracleScene.load(path).prims(), ptmi.HostScene.load(path).prims()):
+        assert (got["type"] == want["type"]).all()
+        tri = got["type"] == 0
+        assert (bits(got["verts"][tri][:, :3]) == bits(want["verts"][tri][:, :3])).all() and (bits(got["verts"][~tri]) == bits(want["verts"][~tri])).all()
+        for k in ("normal", "bsdf", "Le"):
+            assert (bits(got[k]) == bits(want[k])).all(), k
