@@ -48,7 +48,7 @@ SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9             # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 # tools/gather_rate.hip on this GPU (profiles/r02_gather_rate.txt): dependent random fetches of 32-byte records, 28 active lanes
 # per wave, ~50 VALU instructions between fetches - 2.20e11 /s from a 20 MB table, 1.84e11 /s from a 120 MB one, the same at 3 and
 # at 8 waves per SIMD: the ceiling the large-scene walk runs against (its records: 20 MB of nodes, 36 MB of triangles, 16 MB of
@@ -64,6 +64,10 @@ CONFIGS = {
                    served_from="l2/mall/hbm", what="BASELINE configs[4], one GPU's share (rank 3 of 8) at 64 of 2048 spp"),
     "c5frame": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
                     served_from="l2/mall/hbm", what="BASELINE configs[4], the WHOLE frame on one GPU at 64 of 2048 spp: the same kernel with a full GPU"),
+    "c5tile_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_wide", fast=True,
+                        served_from="l2/mall/hbm", what="c5tile through the opt-in fast tree (ptmi_config.fast_tree: 8-wide SAH tree, same triangles and hit arithmetic)"),
+    "c5frame_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
+                         served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
     "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
@@ -227,7 +231,8 @@ def roofline_block(name, cfg, m, exact_workload):
 def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pipelined=True):
     """counters frame (untimed, stats build) + warmup + `steps` timed frames of the loaded workload.
     run_steps(k, stats, pipelined) renders k steps (frames) and returns the list of their ptmi_stats."""
-    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False)
+    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False,
+                 fast_tree=bool(cfg.get("fast")))
     st_counts = r.render_frame()
     quads = r.scene_info()["n_quads"] > 0
     bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
@@ -381,7 +386,7 @@ def main():
 
     pipelined = args.pipeline
     if args.profile_pass:
-        r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=args.segments, collect_stats=False)
+        r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=args.segments, collect_stats=False, fast_tree=bool(cfg.get("fast")))
         run_steps(args.steps, False, pipelined)
         print(json.dumps({"profile_pass": name, "frames": args.steps, **ptmi_buildinfo.stamps()}), flush=True)
         r.close()
@@ -436,11 +441,28 @@ def main():
     # N = 1, headline configuration: the other single-GPU workloads of BASELINE.json, driver-timed in the same run
     if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
         extras = []
-        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5frame", 2)):
+        loaded = None
+        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_fast", 6), ("c5frame", 2), ("c5frame_fast", 3)):
             xcfg = dict(CONFIGS[xname])
-            if xname != "c5frame":                    # c5frame reuses the scene c5tile just loaded
-                load_scene(r, xcfg["scene"])
+            if xcfg["scene"] != loaded:                   # the four 1 M-triangle workloads share one load
+                load_scene(r, xcfg["scene"]); loaded = xcfg["scene"]
             allocate(xcfg)
+            vs_exact = None
+            if xcfg.get("fast"):
+                # what the opt-in tree changes in the result, measured on this very workload: one frame through the exact walk and
+                # one through the fast tree from the same RNG state (update_resolution re-seeds), compared pixel by pixel
+                frames = []
+                for fast in (False, True):
+                    allocate(xcfg)
+                    r.set_config(spp=xcfg["spp"], max_depth=xcfg["max_depth"], segments_per_launch=0, collect_stats=False, fast_tree=fast)
+                    r.render_frame(want_stats=False)
+                    frames.append(r.read_image(rgb8=False)[1])
+                diff = frames[0].view(np.uint32) != frames[1].view(np.uint32)
+                vs_exact = {"pixels": int(frames[0].shape[0] * frames[0].shape[1]), "pixels_differ": int(diff.any(axis=-1).sum()),
+                            "max_abs": float(np.abs(frames[0].astype(np.float64) - frames[1]).max()),
+                            "rmse": float(np.sqrt(np.mean((frames[0].astype(np.float64) - frames[1]) ** 2))),
+                            "what": "float radiance of one frame of this workload, fast tree vs the reference's tree, same RNG state (bar: RMSE < 1e-4)"}
+                allocate(xcfg)
             xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps
             tiled = f", rank {xcfg['tiling'][1]} of {xcfg['tiling'][0]}" if xcfg["tiling"] else ""
@@ -448,6 +470,9 @@ def main():
                            "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "steps": xsteps, "warmup": 1,
                            "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"],
                            "roofline": roofline_block(xname, xcfg, xm, True)})
+            if vs_exact:
+                extras[-1]["fast_tree_vs_exact"] = vs_exact
+        r.set_config(fast_tree=False)
         out["extra_configs"] = extras
 
     if rank == 0:

@@ -813,6 +813,12 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     for (int i = threadIdx.x; i < 8 * n_top; i += kBlock) top[i] = a.sc.wnodes[i];
     uint2* stack = reinterpret_cast<uint2*>(top + 8 * n_top) + threadIdx.x;
     __syncthreads();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 LdsU4;
+    typedef __attribute__((address_space(1))) u32x4 GlobalU4;
+    auto u4 = [](u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); };
+    const LdsU4* top_lds = (const LdsU4*)top;
+    const GlobalU4* wnodes_g = (const GlobalU4*)a.sc.wnodes;
     const MatSource ms = MatSource{a.sc.wmats, a.sc.wmtab, a.sc.wload_index};
     if (GUIDED) fill_grid_solid_angles();
 
@@ -851,12 +857,13 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
                 uint4 q0, q1, q2, q3, q4, q5, q6;
                 if ((int)ni < n_top) {
-                    const uint4* q = top + 8 * ni;
-                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
+                    // explicit address spaces: left generic, the two branches are merged into ONE flat_load through a selected pointer
+                    const LdsU4* q = top_lds + 8 * ni;
+                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
                     if (STATS) cn.top_visits++;
                 } else {
-                    const uint4* q = a.sc.wnodes + 8 * (size_t)ni;
-                    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4]; q5 = q[5]; q6 = q[6];
+                    const GlobalU4* q = wnodes_g + 8 * (size_t)ni;
+                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
                 }
                 if (STATS) cn.node_visits++;
                 const WideStep st = wide_node_test(q0, q1, q2, q3, q4, q5, q6, p.o, inv, octinv, t_min, closest_t);
@@ -903,8 +910,11 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     if (active) store_path(a.st, slot, p);
     finish_launch<STATS>(a, alive, slot, cn);
 }
+#ifndef PTMI_WIDE_WAVES
+#define PTMI_WIDE_WAVES 4
+#endif
 template <bool STATS, bool GUIDED, bool BATCH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
+__global__ __launch_bounds__(kBlock, PTMI_WIDE_WAVES) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
     bounce_wide_body<STATS, GUIDED, BATCH>(a);
 }
 

@@ -62,6 +62,22 @@ PT_HD float wb_min3(float a, float b, float c) {
     return fminf(fminf(a, b), c);
 #endif
 }
+// fmaxf / fminf of two operands that are never NaN here (clamped slopes): on the device without the canonicalising
+// v_max_f32 x, x, x the compiler puts in front of fmaxf / fminf
+PT_HD float wb_max(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fmaxf(a, b);
+#endif
+}
+PT_HD float wb_min(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+    return fminf(a, b);
+#endif
+}
 PT_HD float wb_byte(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xffu); }      // v_cvt_f32_ubyte<i>
 
 // 1 / d, finite: a zero (or denormal-small) direction component becomes a huge finite slope of the same sign
@@ -105,8 +121,8 @@ PT_HD WideStep wide_node_test(uint4 q0, uint4 q1, uint4 q2, uint4 q3, uint4 q4, 
         const float tx0 = __builtin_fmaf(wb_byte(ex_[j], b), sx, bx), tx1 = __builtin_fmaf(wb_byte(fx_[j], b), sx, bx);
         const float ty0 = __builtin_fmaf(wb_byte(ey_[j], b), sy, by), ty1 = __builtin_fmaf(wb_byte(fy_[j], b), sy, by);
         const float tz0 = __builtin_fmaf(wb_byte(ez_[j], b), sz, bz), tz1 = __builtin_fmaf(wb_byte(fz_[j], b), sz, bz);
-        const float tn = wb_max3(tx0, ty0, fmaxf(tz0, t_min));
-        const float tf = wb_min3(tx1, ty1, fminf(tz1, closest));
+        const float tn = wb_max3(tx0, ty0, wb_max(tz0, t_min));
+        const float tf = wb_min3(tx1, ty1, wb_min(tz1, closest));
         hw |= tn <= tf ? w[i] : 0u;
     }
     WideStep s;

@@ -15,9 +15,18 @@ ROOT = os.path.dirname(PKG)
 # everything that reaches build/kernels.o (csrc/kernels.hip and what it includes) + the flags it is compiled with
 KERNEL_SOURCES = [
     os.path.join(PKG, "csrc", "kernels.hip"), os.path.join(PKG, "csrc", "pt_device.h"), os.path.join(PKG, "csrc", "pt_vec.h"),
-    os.path.join(PKG, "csrc", "device_scene.h"), os.path.join(ROOT, "include", "ptmi_math.h"), os.path.join(PKG, "Makefile"),
+    os.path.join(PKG, "csrc", "device_scene.h"), os.path.join(PKG, "csrc", "wide_bvh.h"), os.path.join(ROOT, "include", "ptmi_math.h"),
+    os.path.join(PKG, "Makefile"),
     # the host loop that decides how the kernels are launched (chunks, run-ahead, segments per launch)
     os.path.join(PKG, "host", "application_state.cpp"),
+    # the builder of the opt-in fast tree: the tree's shape decides what ptmi_bounce_wide fetches
+    os.path.join(PKG, "host", "wide_bvh.cpp"),
+]
+# everything that reaches build/radiosity.o (the radiosity pre-pass kernels) + its flags + the host code that launches them
+SOLVER_SOURCES = [
+    os.path.join(PKG, "csrc", "radiosity.hip"), os.path.join(PKG, "csrc", "pt_device.h"), os.path.join(PKG, "csrc", "pt_vec.h"),
+    os.path.join(PKG, "csrc", "device_scene.h"), os.path.join(PKG, "csrc", "wide_bvh.h"), os.path.join(ROOT, "include", "ptmi_math.h"),
+    os.path.join(PKG, "Makefile"), os.path.join(PKG, "host", "application_state.cpp"),
 ]
 
 
@@ -42,14 +51,22 @@ def kernel_src_sha256():
     return _sha(KERNEL_SOURCES)
 
 
+def solver_src_sha256():
+    return _sha(SOLVER_SOURCES)
+
+
 def stamps():
-    return {"lib_sha256": lib_sha256(), "kernel_src_sha256": kernel_src_sha256()}
+    return {"lib_sha256": lib_sha256(), "kernel_src_sha256": kernel_src_sha256(), "solver_src_sha256": solver_src_sha256()}
 
 
-def profile_is_current(profile):
-    """(current?, which stamp matched)"""
+def profile_is_current(profile, solver=False):
+    """(current?, which stamp matched).  solver: the profile describes the radiosity pre-pass kernels (csrc/radiosity.hip)"""
     if profile.get("lib_sha256") and profile.get("lib_sha256") == lib_sha256():
         return True, "lib"
+    if solver:
+        if profile.get("solver_src_sha256") and profile.get("solver_src_sha256") == solver_src_sha256():
+            return True, "solver_sources"
+        return False, None
     if profile.get("kernel_src_sha256") and profile.get("kernel_src_sha256") == kernel_src_sha256():
         return True, "kernel_sources"
     return False, None

@@ -1,0 +1,9 @@
+#!/bin/bash
+# one gpurun call: fast-tree probe with the shipped build and the A/B builds
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+set -e
+for L in "" w5 w6; do
+  if [ -n "$L" ]; then export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so; fi
+  echo "== lib ${L:-shipped}"
+  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:80:0" 3
+done

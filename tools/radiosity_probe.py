@@ -1,11 +1,20 @@
-"""Timing probe for the radiosity pre-pass: python tools/radiosity_probe.py [sub ...] [--oracle] [--p2p] [--samples N]"""
+"""Timing probe for the radiosity pre-pass: python tools/radiosity_probe.py [sub ...] [--oracle] [--p2p] [--samples N]
+   --check-profile FILE : only check that FILE (profiles/rNN_pmc_radiosity.json) was taken from the solver kernels that are built
+                          now (stamps of ptmi_buildinfo: the library, or the sources compiled into build/radiosity.o); exit 1 if not"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cuda-pathtracer_amd", "python"), os.path.join(ROOT, "tests")]
 import ptmi
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if "--check-profile" in sys.argv:
+    import json, ptmi_buildinfo
+    path = sys.argv[sys.argv.index("--check-profile") + 1]
+    ok, how = ptmi_buildinfo.profile_is_current(json.load(open(path)), solver=True)
+    print(f"{path}: {'current (matched by ' + how + ')' if ok else 'STALE: taken from other solver kernels than the ones built now - re-take it (tools/profile_rad.sh)'}")
+    sys.exit(0 if ok else 1)
+
+args = [a for a in sys.argv[1:] if not a.startswith("--") and a.isdigit()]
 subs = [int(a) for a in args] or [2, 3, 4]
 want_oracle = "--oracle" in sys.argv
 kw = {}
