@@ -603,7 +603,7 @@ int ptmi_debug_set_fast_tree(ptmi_ctx* c, int max_leaf, float c_trav, float c_tr
         s.wide_params.max_leaf = max_leaf; s.wide_params.c_trav = c_trav; s.wide_params.c_tri = c_tri; s.wide_top_nodes = top_nodes;
         if (s.d_nodes && !s.num_quads) s.buildFast();
         if (n_nodes) *n_nodes = s.d_scene.w_nodes;
-        if (depth) *depth = s.d_scene.w_depth;
+        if (depth) *depth = s.h_wide.depth;
         if (n_top) *n_top = s.d_scene.w_top;
     });
 }
@@ -641,6 +641,14 @@ int ptmi_host_fast_tree_build(ptmi_host_scene* s, int max_leaf, float c_trav, fl
         if (n_nodes) *n_nodes = sc.h_wide.n_nodes;
         if (depth) *depth = sc.h_wide.depth;
         if (sah) *sah = sc.h_wide.sah;
+    });
+}
+int ptmi_host_fast_tree_stats(const ptmi_host_scene* s, int* out13) {
+    return guarded([&] {
+        need(s && out13, "NULL argument");
+        need(!s->scene.h_wide.empty(), "no fast tree built (ptmi_host_fast_tree_build)");
+        for (int i = 0; i < 9; i++) out13[i] = s->scene.h_wide.fill_hist[i];
+        for (int i = 0; i < 4; i++) out13[9 + i] = s->scene.h_wide.leaf_hist[i];
     });
 }
 int ptmi_host_fast_tree_intersect(const ptmi_host_scene* s, int n, const float* o, const float* d, float t_min, float t_max,

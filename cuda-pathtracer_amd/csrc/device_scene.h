@@ -62,7 +62,7 @@ struct DeviceScene {
     // fast tree's own leaf order ("fast order")
     const uint4* wnodes = nullptr;     // 8 uint4 per node
     int w_nodes = 0, w_top = 0;        // nodes < w_top (whole levels) are staged into LDS by every workgroup
-    int w_depth = 0;                   // levels of the tree = entries of the walk's per-lane LDS stack
+    int w_depth = 0;                   // entries of the walk's per-lane LDS stack = levels of the tree - 1
     const float* wprims = nullptr;     // 9 floats (v0, e1, e2) per fast-order triangle
     const float4* wmats = nullptr;     // (normal.xyz, bits(row of mtab)) per fast-order triangle
     const float4* wmtab = nullptr;     // distinct (Kd, Ke) pairs, 2 float4 per row
@@ -140,10 +140,15 @@ void launch_frame_begin(const TileMap& tm, const PathState& st, const FrameParam
 // pointer, may be nullptr) holds the exact length of queue_in when the host only knows the upper bound n_in: the
 // host can then enqueue launches ahead of the counts coming back.
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus);
+// Count publishing: with host_count set, the last workgroup of the launch to finish stores the output count to *host_count
+// (host-mapped pinned memory; the host polls it), zeroes *next_count (the next launch's counter) and *done_count (its own
+// arrival counter): no fill or copy command between two launches of a chunk.  All three nullptr: the host resets and reads.
+struct CountPublish { int* done_count = nullptr; int* next_count = nullptr; int* host_count = nullptr; };
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */,
-                   bool many_waves /* more waves than bounce_resident_waves(): an 8-wave build where there is one */, hipStream_t s);
+                   bool many_waves /* more waves than bounce_resident_waves(): an 8-wave build where there is one */, hipStream_t s,
+                   const CountPublish& pub = CountPublish());
 // render_radiosity (integrator.h:460-504): the alternative "Radiosity" integrator of renderFrame (application.h:193-197):
 // spp camera rays per pixel, first hit only, Le + per-primitive radiosity, sqrt gamma, 8-bit (+ float mean).
 void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,

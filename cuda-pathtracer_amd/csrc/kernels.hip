@@ -351,6 +351,12 @@ struct BounceArgs {
     int segments;
     StatCounters* stats;
     int many_waves;                         // 1: more waves than the device holds at once (picks the 8-wave build of the packed walk)
+    // count publishing (nullptr: off): the LAST workgroup of the launch to finish stores the launch's output count to a
+    // host-mapped pinned slot and zeroes the next launch's counter, so a chunk's stream carries kernels only - no fill and
+    // no 4-byte copy between two launches, each of which waits for a CU slot on a saturated GPU (r02: 11 % of c5frame)
+    int* done_count;                        // workgroups of this launch that have finished (device memory, zero between launches)
+    int* next_count;                        // the counter the next launch of this chunk will add to
+    int* host_count;                        // pinned host memory, device address
 };
 
 // Per-lane path registers (the 88-byte HBM record, unpacked).
@@ -613,6 +619,24 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
     }
 }
 
+// Tail of every bounce kernel when count publishing is on: every WAVE of the grid passes here exactly once (also the ones
+// that found nothing to do), after its own reservation in count_out - no workgroup barrier, a finished wave leaves at once
+// (with a barrier in front of one arrival per workgroup the waves that finish early keep their registers until the
+// workgroup's slowest is through: whole 1 M-triangle frame -4 %).  count_out is only ever touched by device-scope atomics,
+// so the last arrival reads the sum.
+__device__ __forceinline__ void publish_count(const BounceArgs& a) {
+    if (!a.host_count) return;
+    if ((threadIdx.x & 63) == 0) {
+        __threadfence();
+        if (atomicAdd(a.done_count, 1) == (int)(gridDim.x * (kBlock / 64)) - 1) {
+            const int c = atomicAdd(a.count_out, 0);
+            atomicExch(a.next_count, 0);
+            atomicExch(a.done_count, 0);
+            __hip_atomic_store(a.host_count, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---- ptmi_bounce: segment-synchronous form (SWEEP and STACK walks) ------------------------------------------------
 // Every wave traces one ray segment per lane, then shades, K times.  LDS: [nodes | prims | mats] when LDS_GEOM (always
 // for SWEEP), then the traversal stacks (STACK only).
@@ -621,7 +645,7 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
 // GUIDED instantiations would take ~100 VGPRs (4 waves per SIMD); capped at 80 (6 waves, 68 bytes of spills): grid
 // sampling +13 %, MIS +9 % on the benchmark frame (5 waves +8 %, 7 the same as 6, 8 waves +10 % / +3 %).
 template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool BATCH>
-__global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SWEEP ? 8 : 1)) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
+__device__ __forceinline__ void bounce_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -651,6 +675,11 @@ __global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SW
 
     if (active) store_path(a.st, slot, p);
     finish_launch<STATS>(a, alive, slot, cn);
+}
+template <int MODE, bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool BATCH>
+__global__ __launch_bounds__(kBlock, GUIDED ? 6 : (BATCH && MODE == TRAVERSAL_SWEEP ? 8 : 1)) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce(BounceArgs a) {
+    bounce_body<MODE, LDS_GEOM, HAS_QUADS, STATS, GUIDED, BATCH>(a);
+    publish_count(a);
 }
 
 // ---- ptmi_bounce_phased: wave-scheduled phases (LANE walk for large scenes) -----------------------------------------
@@ -785,6 +814,7 @@ __device__ __forceinline__ void bounce_phased_body(const BounceArgs& a) {
 template <bool LDS_GEOM, bool HAS_QUADS, bool STATS, bool GUIDED, bool PACKED, bool BATCH>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_phased(BounceArgs a) {
     bounce_phased_body<LDS_GEOM, HAS_QUADS, STATS, GUIDED, PACKED, BATCH>(a);
+    publish_count(a);
 }
 // The packed walk of a triangle scene, BSDF sampling, bounded to 8 waves per SIMD (64 VGPRs, 11 spilled outside the walk
 // loop): for frames with more waves than the device holds, where a wave more per SIMD is worth +5 % (whole 1 M-triangle frame
@@ -793,6 +823,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void p
 template <bool STATS, bool BATCH>
 __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_packed_w8(BounceArgs a) {
     bounce_phased_body<false, false, STATS, false, true, BATCH>(a);
+    publish_count(a);
 }
 
 
@@ -803,6 +834,9 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // triangles of hit leaf children a 24-bit mask that the following PRIM steps test one by one.  Stack: one (child_base,
 // imask << 8 | pending) pair per tree level in LDS, entry e of lane l at stack[e * kBlock + l] - conflict-free whatever e.
 // The triangle test is the exact walk's (mt_hit = mt_accept's arithmetic); equal-t hits keep the smaller reference slot.
+// Measured and dropped: a UNIFIED step (a lane's pending triangle and its next node fetched and tested in one step, two phases
+// to vote between): 92 registers, 5 waves per SIMD: 1 610 / 2 322 Msamples/s (an eighth / the whole 1 M-triangle frame) against
+// 1 719 / 2 405 for this form at 6 waves; bounded to 6 waves it spills inside the loop (867 / 1 100).
 template <bool STATS, bool GUIDED, bool BATCH>
 __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
@@ -911,11 +945,12 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     finish_launch<STATS>(a, alive, slot, cn);
 }
 #ifndef PTMI_WIDE_WAVES
-#define PTMI_WIDE_WAVES 4
+#define PTMI_WIDE_WAVES 6
 #endif
 template <bool STATS, bool GUIDED, bool BATCH>
 __global__ __launch_bounds__(kBlock, PTMI_WIDE_WAVES) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
     bounce_wide_body<STATS, GUIDED, BATCH>(a);
+    publish_count(a);
 }
 
 #ifdef PTMI_TRACE_WAVES
@@ -1013,16 +1048,18 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
-                   StatCounters* stats, bool many_waves, hipStream_t s) {
+                   StatCounters* stats, bool many_waves, hipStream_t s, const CountPublish& pub) {
     if (n_in <= 0) return;
-    BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats, many_waves ? 1 : 0};
+    BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats, many_waves ? 1 : 0,
+                 pub.done_count, pub.next_count, pub.host_count};
     const dim3 grid((n_in + kBlock - 1) / kBlock);
     with_bounce_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 
 // waves of the frame's bounce kernel that the device holds at once (0: unknown)
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
-    BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr, 0};
+    BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr, 0,
+                 nullptr, nullptr, nullptr};
     int blocks = 0;
     with_bounce_kernel(a, [&](auto kernel, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;

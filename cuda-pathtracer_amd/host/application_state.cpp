@@ -357,9 +357,16 @@ void SceneState::buildFast() {
     d_wmtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_wmtab");
     d_wload_index = (int*)upload_vec(h_wide.tri_load_index.data(), (size_t)n * sizeof(int), "d_wload_index");
     d_wref_slot = (int*)upload_vec(ref_slot.data(), (size_t)n * sizeof(int), "d_wref_slot");
-    int top = 0;                                       // whole levels while they fit
-    for (size_t l = 1; l < h_wide.level_start.size(); l++) if (h_wide.level_start[l] <= wide_top_nodes) top = h_wide.level_start[l];
-    d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = h_wide.depth;
+    // LDS of a workgroup: the walk's stack (one 8-byte entry per lane and tree level below the root: a group is pushed only
+    // while a deeper one is entered) + the top of the tree, whole levels while they fit wide_top_nodes AND six workgroups
+    // still share a CU's 160 KB (6 waves per SIMD, what the kernel's 80 registers allow; a 9-level tree with the 8-level
+    // tree's top dropped to 5 waves: -6 %)
+    const int stack_entries = std::max(h_wide.depth - 1, 1);
+    const long long lds_budget = 160 * 1024 / 6 - (long long)stack_entries * kBlock * 8;
+    int top = 0;
+    for (size_t l = 1; l < h_wide.level_start.size(); l++)
+        if (h_wide.level_start[l] <= wide_top_nodes && (long long)h_wide.level_start[l] * kWideNodeDwords * 4 <= lds_budget) top = h_wide.level_start[l];
+    d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = stack_entries;
     d_scene.wprims = d_wprims; d_scene.wmats = d_wmats; d_scene.wmtab = d_wmtab; d_scene.wload_index = d_wload_index; d_scene.wref_slot = d_wref_slot;
 }
 
@@ -593,7 +600,7 @@ void RenderState::freeBuffers() {
         void* cp[] = {c.d_queue_init, c.d_queue[0], c.d_queue[1], c.d_count};
         for (void* p : cp) if (p) (void)hipFree(p);
         if (c.h_count) (void)hipHostFree(c.h_count);
-        c.d_queue_init = c.d_queue[0] = c.d_queue[1] = c.d_count = nullptr; c.h_count = nullptr; c.n = 0;
+        c.d_queue_init = c.d_queue[0] = c.d_queue[1] = c.d_count = nullptr; c.h_count = nullptr; c.d_hcount = nullptr; c.n = 0;
     }
     d_state = PathState();
     d_image = nullptr; d_radiance = nullptr; d_stats = nullptr;
@@ -631,8 +638,11 @@ void RenderState::allocateBuffers() {
         ch.d_queue_init = (int*)hipMallocSafe(cap, "chunk.queue_init");
         ch.d_queue[0] = (int*)hipMallocSafe(cap, "chunk.queue0");
         ch.d_queue[1] = (int*)hipMallocSafe(cap, "chunk.queue1");
-        ch.d_count = (int*)hipMallocSafe(kCountRing * sizeof(int), "chunk.count");
-        PTMI_HIP(hipHostMalloc((void**)&ch.h_count, kCountRing * sizeof(int)));
+        ch.d_count = (int*)hipMallocSafe((kCountRing + 1) * sizeof(int), "chunk.count");      // + the launch's arrival counter
+        PTMI_HIP(hipMemset(ch.d_count, 0, (kCountRing + 1) * sizeof(int)));
+        // coherent (fine-grained) host memory: with count publishing the device stores into it while the kernel runs
+        PTMI_HIP(hipHostMalloc((void**)&ch.h_count, kCountRing * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+        PTMI_HIP(hipHostGetDevicePointer((void**)&ch.d_hcount, ch.h_count, 0));
         if (ch.n) PTMI_HIP(hipMemcpy(ch.d_queue_init, slots[c].data(), slots[c].size() * sizeof(int), hipMemcpyHostToDevice));
     }
 
@@ -778,6 +788,14 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         }
     } drain{r};
     const bool want_stats = g.config.collect_stats;
+    // Count publishing (device_scene.h: CountPublish): the launch's last wave stores the output count to
+    // pinned host memory and zeroes the next counter, so a chunk's stream carries kernels only - no fill and no 4-byte copy
+    // between two launches (profiles/r02_kernel_stats_c5frame.csv: copyBuffer 11.2 % of the summed GPU time).  Built, parity
+    // green (100 GPU tests with it on), and measured SLOWER where it was meant to help: whole 1 M-triangle frame, exact walk
+    // 245.5 -> 262.0 ms, fast tree 120.5 -> 125.4 ms; an eighth of the frame +-0.  The blits' time is waiting
+    // time behind the other chunk's kernel, not GPU time the frame is short of.  Off by default; PTMI_PUBLISH=1 turns it on.
+    bool publish = false;
+    if (const char* e = getenv("PTMI_PUBLISH")) publish = e[0] == '1';
 
     auto event = [&](size_t i) {
         while (g.event_pool.size() <= i) { hipEvent_t ev; PTMI_HIP(hipEventCreate(&ev)); g.event_pool.push_back(ev); }
@@ -823,6 +841,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         run[c].bound = r.chunk[c].n; run[c].finished = r.chunk[c].n == 0;
         for (int i = 0; i < kRing; i++) run[c].done[i] = event(n_ev++);
         PTMI_HIP(hipStreamWaitEvent(r.chunk[c].stream, ev_ready, 0));
+        if (publish) PTMI_HIP(hipMemsetAsync(r.chunk[c].d_count, 0, (kRing + 1) * sizeof(int), r.chunk[c].stream));   // once per frame
     }
     uint64_t launches = 0, visits = 0;
     const size_t first_pair_event = n_ev;
@@ -832,7 +851,11 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
             Run& u = run[c]; RenderState::Chunk& ch = r.chunk[c];
             while (!u.finished && u.issued - u.retired < kRunAhead) {
                 const int slot_out = u.issued % kRing;
-                PTMI_HIP(hipMemsetAsync(ch.d_count + slot_out, 0, sizeof(int), ch.stream));
+                CountPublish pub;
+                if (publish) {
+                    pub.done_count = ch.d_count + kRing; pub.next_count = ch.d_count + (slot_out + 1) % kRing; pub.host_count = ch.d_hcount + slot_out;
+                    __atomic_store_n(ch.h_count + slot_out, -1, __ATOMIC_RELEASE);      // "not there yet"
+                } else PTMI_HIP(hipMemsetAsync(ch.d_count + slot_out, 0, sizeof(int), ch.stream));
                 const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
                 long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
@@ -841,12 +864,14 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
                               fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr,
-                              phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream);
+                              phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream, pub);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
-                PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
-                PTMI_HIP(hipEventRecord(u.done[slot_out], ch.stream));
+                if (!publish) {
+                    PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
+                    PTMI_HIP(hipEventRecord(u.done[slot_out], ch.stream));
+                }
                 u.issued++;
             }
         }
@@ -854,7 +879,21 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
             Run& u = run[c]; RenderState::Chunk& ch = r.chunk[c];
             if (u.retired == u.issued) continue;
             const int slot = u.retired % kRing;
-            PTMI_HIP(hipEventSynchronize(u.done[slot]));
+            if (publish) {
+                // the launch's last workgroup stores the count here; the stream is asked now and then so that a launch that
+                // died (or never ran) surfaces as an error instead of an endless wait
+                unsigned long long spins = 0;
+                while (__atomic_load_n(ch.h_count + slot, __ATOMIC_ACQUIRE) < 0) {
+                    if ((++spins & 0xffffu) == 0) {
+                        const hipError_t q = hipStreamQuery(ch.stream);
+                        if (q != hipErrorNotReady && __atomic_load_n(ch.h_count + slot, __ATOMIC_ACQUIRE) < 0) {
+                            if (q != hipSuccess) throw HipError(q, std::string("bounce launch failed: ") + hipGetErrorString(q));
+                            throw HipError(hipErrorUnknown, "bounce launch finished without publishing its count");
+                        }
+                    }
+                    __builtin_ia32_pause();
+                }
+            } else PTMI_HIP(hipEventSynchronize(u.done[slot]));
             const int out_count = ch.h_count[slot];
             launches++;                                // every issued launch counts (rocprof sees the trailing empty ones too)
             if (u.retired == 0 || u.last_out > 0) visits += (uint64_t)(u.retired == 0 ? ch.n : u.last_out);

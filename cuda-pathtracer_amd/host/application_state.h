@@ -169,7 +169,8 @@ struct RenderState {
         hipStream_t stream = nullptr;
         int n = 0;                                   // pixels in this chunk
         int *d_queue_init = nullptr, *d_queue[2] = {nullptr, nullptr}, *d_count = nullptr;
-        int* h_count = nullptr;                      // pinned, kCountRing entries
+        int* h_count = nullptr;                      // pinned + coherent, kCountRing entries
+        int* d_hcount = nullptr;                     // the same memory as the device addresses it (count publishing)
     } chunk[kMaxChunks];
     int n_chunks = 1;
     int want_chunks = 0;                             // 0 = automatic, else forced (scheduling knob)

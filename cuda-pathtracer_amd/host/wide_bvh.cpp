@@ -25,7 +25,7 @@ struct Box {
     }
 };
 
-struct Node2 { Box box; int left = -1, right = -1, first = 0, count = 0; };    // count > 0: leaf over order[first .. first + count)
+struct Node2 { Box box; int left = -1, right = -1, first = 0, count = 0, r_first = 0, r_count = 0; };   // count > 0: leaf; r_*: the subtree's range of order[]
 
 struct Builder2 {
     const std::vector<Box>& pbox;
@@ -52,7 +52,7 @@ struct Builder2 {
             const Job j = jobs.back(); jobs.pop_back();
             Box bounds, cb;
             for (int i = j.first; i < j.first + j.count; i++) { bounds.grow(pbox[order[i]]); cb.grow(pcen[order[i]].data()); }
-            nodes[j.node].box = bounds;
+            nodes[j.node].box = bounds; nodes[j.node].r_first = j.first; nodes[j.node].r_count = j.count;
             auto make_leaf = [&] { nodes[j.node].first = j.first; nodes[j.node].count = j.count; };
             if (j.count == 1) { make_leaf(); continue; }
             // binned SAH over the three axes in one pass
@@ -145,27 +145,68 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
     out.binary_nodes = (int)N.size();
     for (const Node2& x : N) if (x.count > 0) out.binary_leaves++;
 
-    // ---- collapse: a wide node takes up to 8 descendants of its binary node, always opening the largest inner one next ----
-    struct WNode { int bin; int child[8]; int n_child = 0; int level = 0; };
+    // ---- collapse by dynamic programming over the binary tree (the published scheme of Ylitie, Karras, Laine 2017, sec. 3.1) ----
+    // cost(n, i) = least SAH cost of standing the subtree of binary node n on at most i slots of a wide node:
+    //   as ONE leaf child (all its triangles, if there are at most max_leaf):  area(n) * triangles(n) * c_tri
+    //   as ONE inner child (a wide node of its own):                            area(n) * c_trav + distribute(n, 8)
+    //   distribute(n, j) = min over k of cost(left, k) + cost(right, j - k);    cost(n, i) = min(distribute(n, i), cost(n, i - 1))
+    // The greedy alternative (always open the largest child) left 35 % of the 1 M-triangle scene's nodes with two children.
+    const int nb2 = (int)N.size();
+    const double INF = std::numeric_limits<double>::infinity();
+    struct Dp { double c[8]; uint8_t split[9]; uint8_t leaf1; };        // c[i], i = 1..7; split[j], j = 2..8: slots given to the left child
+    std::vector<Dp> dp((size_t)nb2);
+    for (int x = nb2 - 1; x >= 0; x--) {
+        Dp& d = dp[(size_t)x];
+        const double area = N[x].box.area();
+        const int tris = N[x].r_count;
+        const double as_leaf = tris <= prm.max_leaf ? area * tris * (double)prm.c_tri : INF;
+        if (N[x].count > 0) {                                            // binary leaf
+            for (int i = 1; i <= 7; i++) d.c[i] = as_leaf;
+            d.leaf1 = 1;
+            continue;
+        }
+        const Dp &l = dp[(size_t)N[x].left], &r = dp[(size_t)N[x].right];
+        double dist[9];
+        for (int j = 2; j <= 8; j++) {
+            dist[j] = INF; d.split[j] = 1;
+            for (int k = 1; k < j; k++) {
+                const double c = l.c[std::min(k, 7)] + r.c[std::min(j - k, 7)];
+                if (c < dist[j]) { dist[j] = c; d.split[j] = (uint8_t)k; }
+            }
+        }
+        const double as_inner = area * (double)prm.c_trav + dist[8];
+        d.leaf1 = as_leaf <= as_inner ? 1 : 0;
+        d.c[1] = std::min(as_leaf, as_inner);
+        for (int i = 2; i <= 7; i++) d.c[i] = std::min(dist[i], d.c[i - 1]);
+    }
+    struct WNode { int bin; int level; };
     std::vector<WNode> W;
     W.reserve(N.size() / 4 + 2);
-    W.push_back({0, {}, 0, 1});
+    W.push_back({0, 1});
     out.level_start.push_back(0);
     out.tri_load_index.reserve((size_t)n);
     std::vector<uint32_t>& nodes = out.nodes;
     const double root_area = std::max(N[0].box.area(), 1e-300);
+    std::vector<std::pair<int, int>> todo;
     for (size_t wi = 0; wi < W.size(); wi++) {
         if (W[wi].level > (int)out.level_start.size()) out.level_start.push_back((int)wi);
-        WNode w = W[wi];
+        const WNode w = W[wi];
         int set[8], ns = 0;
-        if (N[w.bin].count > 0) set[ns++] = w.bin;               // a scene of <= max_leaf triangles: the root's only child is a leaf
-        else { set[ns++] = N[w.bin].left; set[ns++] = N[w.bin].right; }
-        while (ns < 8) {
-            int pick = -1; double pa = -1.0;
-            for (int k = 0; k < ns; k++) if (N[set[k]].count == 0) { const double a = N[set[k]].box.area(); if (a > pa) { pa = a; pick = k; } }
-            if (pick < 0) break;
-            const int x = set[pick];
-            set[pick] = N[x].left; set[ns++] = N[x].right;
+        bool set_leaf[8];
+        if (N[w.bin].count > 0) { set[ns] = w.bin; set_leaf[ns++] = true; }       // a scene of <= max_leaf triangles: the root's only child
+        else {
+            // the children of this wide node: walk the recorded decisions from distribute(bin, 8) down
+            todo.clear();
+            const int k = dp[(size_t)w.bin].split[8];
+            todo.push_back({N[w.bin].right, 8 - k}); todo.push_back({N[w.bin].left, k});
+            while (!todo.empty()) {
+                const int x = todo.back().first; int i = std::min(todo.back().second, 7); todo.pop_back();
+                const Dp& d = dp[(size_t)x];
+                if (N[x].count == 0) while (i > 1 && d.c[i] == d.c[i - 1]) i--;      // cost(n, i) came from fewer slots
+                if (i == 1 || N[x].count > 0) { set[ns] = x; set_leaf[ns++] = N[x].count > 0 || d.leaf1; continue; }
+                const int kk = d.split[i];
+                todo.push_back({N[x].right, i - kk}); todo.push_back({N[x].left, kk});
+            }
         }
         // ---- slots: child c goes to the slot whose corner direction its centre lies towards (greedy on the best pairs) ----
         Box nb;
@@ -188,9 +229,9 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
             }
             placed[bc] = true; slot_used[bs] = true; slot_of[bc] = bs;
         }
-        int child_in_slot[8];
-        for (int s = 0; s < 8; s++) child_in_slot[s] = -1;
-        for (int k = 0; k < ns; k++) child_in_slot[slot_of[k]] = set[k];
+        int child_in_slot[8]; bool leaf_in_slot[8];
+        for (int s = 0; s < 8; s++) { child_in_slot[s] = -1; leaf_in_slot[s] = false; }
+        for (int k = 0; k < ns; k++) { child_in_slot[slot_of[k]] = set[k]; leaf_in_slot[slot_of[k]] = set_leaf[k]; }
 
         // ---- record ----
         const size_t base = nodes.size();
@@ -224,14 +265,15 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
                 q[a][s] = (uint8_t)lo; q[3 + a][s] = (uint8_t)hi;
             }
             out.sah += cbx.area() / root_area;
-            if (N[c].count > 0) {
+            if (leaf_in_slot[s]) {
                 const uint32_t off = (uint32_t)out.tri_load_index.size() - tri_base;
-                for (int i = 0; i < N[c].count; i++) out.tri_load_index.push_back(b2.order[N[c].first + i]);
-                rec[WN_WORD0 + s] = ((1u << N[c].count) - 1u) << off;
+                for (int i = 0; i < N[c].r_count; i++) out.tri_load_index.push_back(b2.order[N[c].r_first + i]);
+                rec[WN_WORD0 + s] = ((1u << N[c].r_count) - 1u) << off;
+                out.leaf_hist[N[c].r_count]++;
             } else {
                 imask |= 1u << s;
                 rec[WN_WORD0 + s] = 1u << (24 + s);
-                W.push_back({c, {}, 0, w.level + 1});
+                W.push_back({c, w.level + 1});
             }
         }
         rec[3] = ebias[0] | (ebias[1] << 8) | (ebias[2] << 16) | (imask << 24);
@@ -241,6 +283,7 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
             rec[WN_PLANES0 + 2 * pl + 1] = (uint32_t)q[pl][4] | ((uint32_t)q[pl][5] << 8) | ((uint32_t)q[pl][6] << 16) | ((uint32_t)q[pl][7] << 24);
         }
         out.depth = std::max(out.depth, w.level);
+        out.fill_hist[ns]++;
     }
     out.n_nodes = (int)W.size();
     out.level_start.push_back(out.n_nodes);

@@ -23,6 +23,7 @@ struct WideBVH {
     int n_nodes = 0, depth = 0;         // depth: levels of wide nodes (root = 1) = most entries the walk's stack ever holds + 1
     double sah = 0.0;                   // for inspection: sum of (child area / root area) over all children of all nodes
     int binary_nodes = 0, binary_leaves = 0;
+    int fill_hist[9] = {}, leaf_hist[4] = {};   // nodes by number of children; leaf children by number of triangles
     bool empty() const { return n_nodes == 0; }
     void clear() { *this = WideBVH(); }
 };

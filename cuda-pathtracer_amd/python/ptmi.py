@@ -28,7 +28,7 @@ EXPORTS = [
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
     "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
-    "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect",
+    "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect", "ptmi_host_fast_tree_stats",
 ]
 
 
@@ -146,6 +146,7 @@ def lib():
         L.ptmi_debug_set_fast_tree.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, ip]
         L.ptmi_debug_intersect_fast.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]
         L.ptmi_host_fast_tree_build.argtypes = [vp, C.c_int, C.c_float, C.c_float, ip, ip, C.POINTER(C.c_double)]
+        L.ptmi_host_fast_tree_stats.argtypes = [vp, vp]
         L.ptmi_host_fast_tree_intersect.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         _lib = L
     return _lib
@@ -211,6 +212,11 @@ class HostScene:
         n = C.c_int(); d = C.c_int(); sah = C.c_double()
         _check(lib().ptmi_host_fast_tree_build(self.h, int(max_leaf), float(c_trav), float(c_tri), C.byref(n), C.byref(d), C.byref(sah)))
         return dict(n_nodes=n.value, depth=d.value, sah=sah.value)
+
+    def fast_tree_stats(self):
+        out = np.zeros(13, np.int32)
+        _check(lib().ptmi_host_fast_tree_stats(self.h, out.ctypes.data))
+        return dict(nodes_by_children=out[:9].tolist(), leaves_by_triangles=out[9:].tolist())
 
     def fast_tree_intersect(self, o, d, t_min=1e-4, t_max=3.4028234663852886e38):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)

@@ -331,6 +331,8 @@ int ptmi_debug_intersect_fast(ptmi_ctx*, int n, const float* o, const float* d, 
 /* Host-only halves of the same: build the fast tree of a host scene, and walk it on the CPU decision for decision as the
  * kernel does (tests of the builder without a GPU). */
 int ptmi_host_fast_tree_build(ptmi_host_scene*, int max_leaf, float c_trav, float c_tri, int* n_nodes, int* depth, double* sah);
+/* shape of the built tree: out[0..8] = nodes with that many children, out[9..12] = leaf children with 0..3 triangles */
+int ptmi_host_fast_tree_stats(const ptmi_host_scene*, int* out13);
 int ptmi_host_fast_tree_intersect(const ptmi_host_scene*, int n, const float* o, const float* d, float t_min, float t_max,
                                   int* prim, float* t, uint64_t* counts /* [0] node visits [1] triangle tests [2] deepest stack */);
 /* render_init + curand_uniform: first `count` uniforms of pixel stream (seed_base+pixel, subsequence pixel). */

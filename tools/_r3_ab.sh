@@ -1,9 +1,8 @@
 #!/bin/bash
-# one gpurun call: fast-tree probe with the shipped build and the A/B builds
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
-for L in "" w5 w6; do
+for L in "" uni uni5; do
   if [ -n "$L" ]; then export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so; fi
   echo "== lib ${L:-shipped}"
-  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:80:0" 3
+  timeout -k 10 200 python tools/fast_probe.py 64 "0:3:1:80:0,1:3:1:80:0" 3
 done
