@@ -75,9 +75,9 @@ void ptmi_default_config(ptmi_config* c) {
 void ptmi_default_tiling(ptmi_tiling* t) { t->n_ranks = 1; t->rank = 0; t->row_block = 8; }
 
 int ptmi_ctx_create(int device_id, ptmi_ctx** out) {
-    // multi-process GPU work (the RCCL gather) needs dmabuf IPC on this driver stack; only takes effect if the process has
-    // not initialised HIP yet and does not say otherwise
-    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    // (multi-process GPU work - the RCCL gather - needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver stack.  The CALLER exports it
+    // before anything initialises HIP: a setenv from here would come too late for a process that already has, and races with
+    // getenv in other threads; include/ptmi.h says so at ptmi_dist_init)
     return guarded([&] { need(out != nullptr, "out is NULL"); *out = nullptr; *out = new ptmi_ctx(device_id); });
 }
 void ptmi_ctx_destroy(ptmi_ctx* c) { delete c; }
@@ -545,6 +545,9 @@ int ptmi_dist_allreduce_max(ptmi_ctx* c, double* value) {
         PTMI_HIP(hipSetDevice(c->app.device_id));
         *value = c->app.dist.allreduceMax(*value);
     });
+}
+int ptmi_dist_comm_count(ptmi_ctx* c, int* n_ranks) {
+    return guarded([&] { need(c && n_ranks, "NULL argument"); PTMI_HIP(hipSetDevice(c->app.device_id)); *n_ranks = c->app.dist.commCount(); });
 }
 int ptmi_debug_place_tiles(ptmi_ctx* c, int width, int height, int n_ranks, int row_block, const unsigned char* tiles_rgb8,
                            const float* tiles_radiance, unsigned char* out_rgb8, float* out_radiance) {

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 namespace ptmi {
 
@@ -34,6 +35,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -41,9 +43,8 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
 };
-Rccl& rccl() {
-    static Rccl r;
-    if (r.handle) return r;
+Rccl load_rccl() {
+    Rccl r;                                               // filled completely before anyone can see it
     // PTMI_RCCL_LIB: the file to load instead (a process that has torch in it already holds torch's librccl.so.1, which a bare
     // name would resolve to; the tests' transport stand-in, tests/mock_rccl.cpp, is given by path)
     const char* names[] = {std::getenv("PTMI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -61,12 +62,20 @@ Rccl& rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.Send = (decltype(r.Send))sym("ncclSend");
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    return r;
+}
+// One table per process, published once: a function-local static is initialised under the C++ runtime's guard, so a second
+// rank thread (ptmi.h: "one process or host thread per GPU") either waits for the first one's load or sees the finished
+// table; a load that throws leaves it uninitialised and the next call tries again.
+const Rccl& rccl() {
+    static const Rccl r = load_rccl();
     return r;
 }
 #define PTMI_NCCL(call)                                                                                              \
@@ -79,9 +88,24 @@ Rccl& rccl() {
 // ---------------------------------------------------------------------------------------------
 // row placement: tiles in rank order (each tile = that rank's local rows, local-row-major) -> whole frame
 // ---------------------------------------------------------------------------------------------
-// One thread per output element group: global row y belongs to rank (y / row_block) % n_ranks and is local row
-// (y / (row_block * n_ranks)) * row_block + y % row_block there (ptmi_tiling, include/ptmi.h).  `own` replaces the
-// staging copy of the destination's own tile (it is read straight from the render buffers).
+// Global row y belongs to rank (y / row_block) % n_ranks and is local row (y / (row_block * n_ranks)) * row_block +
+// y % row_block there (ptmi_tiling, include/ptmi.h).  `own` replaces the staging copy of the destination's own tile (it is
+// read straight from the render buffers).  Rows are contiguous in the tile and in the frame, and every tile starts on a
+// 16-byte boundary of the staging buffer (tileOffsets), so while a row is a whole number of 16-byte vectors (width % 16 == 0
+// for the 8-bit image, width % 4 == 0 for float radiance: every BASELINE frame) a row moves as 16-byte vectors: one block row
+// of the grid per frame row - the row arithmetic is scalar, once per workgroup - and one thread per vector.
+__global__ __launch_bounds__(256) void ptmi_place_rows_v16(const uint4* __restrict__ stage, const uint4* __restrict__ own, int own_rank,
+                                                           const long long* __restrict__ tile_offset /* ELEMENTS, per rank */,
+                                                           int elems_per_v16, int vec_per_row, int n_ranks, int row_block, uint4* __restrict__ frame) {
+    const int y = blockIdx.y;
+    const int blk = y / row_block;
+    const int rank = blk % n_ranks;
+    const int lr = (blk / n_ranks) * row_block + (y - blk * row_block);
+    const uint4* src = (rank == own_rank && own ? own : stage + tile_offset[rank] / elems_per_v16) + (long long)lr * vec_per_row;
+    uint4* dst = frame + (long long)y * vec_per_row;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vec_per_row; v += gridDim.x * blockDim.x) dst[v] = src[v];
+}
+// any other width: element by element
 template <typename T>
 __global__ __launch_bounds__(256) void ptmi_place_tiles(const T* __restrict__ stage, const T* __restrict__ own, int own_rank,
                                                         const long long* __restrict__ tile_offset /* elements, per rank */,
@@ -99,11 +123,32 @@ __global__ __launch_bounds__(256) void ptmi_place_tiles(const T* __restrict__ st
     }
 }
 
+// first element of every rank's tile in the staging buffers: exact tile sizes, each start rounded up to 16 elements (so that a
+// tile of bytes and a tile of floats both start on a 16-byte boundary); returns the elements the staging buffer needs
+static long long tileOffsets(int width, int height, int n_ranks, int row_block, std::vector<long long>& off) {
+    off.assign((size_t)n_ranks, 0);
+    long long acc = 0;
+    for (int k = 0; k < n_ranks; k++) {
+        acc = (acc + 15) / 16 * 16;
+        off[k] = acc;
+        acc += (long long)countLocalRows(height, n_ranks, k, row_block) * width * 3;
+    }
+    return acc;
+}
+
 template <typename T>
 static void launch_place(const T* stage, const T* own, int own_rank, const long long* d_off, int w, int h, int n_ranks, int row_block,
                          T* frame, hipStream_t s) {
     const long long total = (long long)w * 3 * h;
     if (total <= 0) return;
+    const long long row_bytes = (long long)w * 3 * (long long)sizeof(T);
+    const bool aligned = ((uintptr_t)stage % 16 == 0) && ((uintptr_t)frame % 16 == 0) && (!own || (uintptr_t)own % 16 == 0);
+    if (row_bytes % 16 == 0 && aligned && h <= 65535) {
+        const int vec_per_row = (int)(row_bytes / 16);
+        hipLaunchKernelGGL(ptmi_place_rows_v16, dim3(std::min((vec_per_row + 255) / 256, 64), h), dim3(256), 0, s, (const uint4*)stage, (const uint4*)own,
+                           own_rank, d_off, (int)(16 / sizeof(T)), vec_per_row, n_ranks, row_block, (uint4*)frame);
+        return;
+    }
     const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
     hipLaunchKernelGGL((ptmi_place_tiles<T>), dim3(blocks), dim3(256), 0, s, stage, own, own_rank, d_off, w, h, n_ranks, row_block, frame);
 }
@@ -132,7 +177,7 @@ void DistState::finalize() {
     if (d_token) { (void)hipFree(d_token); d_token = nullptr; }
     if (gather_done) { (void)hipEventDestroy(gather_done); gather_done = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
-    n_ranks = 1; rank = 0; pending = false;
+    n_ranks = 1; rank = 0; pending = false; failed = false;
 }
 
 void DistState::init(const void* unique_id128, int n, int r) {
@@ -154,27 +199,52 @@ void DistState::ensureFrame(const TileMap& tm, bool want_rgb, bool want_rad) {
     const bool same = frame_w == tm.width && frame_h == tm.height && frame_row_block == tm.row_block && frame_ranks == tm.n_ranks;
     if (!same) freeFrame();
     const size_t px = (size_t)tm.width * (size_t)tm.height;
+    std::vector<long long> off;
+    const size_t stage_elems = (size_t)tileOffsets(tm.width, tm.height, tm.n_ranks, tm.row_block, off);
     if (!d_tile_offset) {
-        std::vector<long long> off((size_t)tm.n_ranks);
-        long long acc = 0;
-        for (int k = 0; k < tm.n_ranks; k++) { off[k] = acc; acc += (long long)countLocalRows(tm.height, tm.n_ranks, k, tm.row_block) * tm.width * 3; }
         d_tile_offset = (long long*)hipMallocSafe(off.size() * sizeof(long long), "dist.tile_offset");
         PTMI_HIP(hipMemcpy(d_tile_offset, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
         h_tile_offset = off;
         frame_w = tm.width; frame_h = tm.height; frame_row_block = tm.row_block; frame_ranks = tm.n_ranks;
     }
     if (want_rgb && !d_frame_rgb) {
-        d_stage_rgb = (unsigned char*)hipMallocSafe(px * 3, "dist.stage_rgb");
+        d_stage_rgb = (unsigned char*)hipMallocSafe(stage_elems, "dist.stage_rgb");
         d_frame_rgb = (unsigned char*)hipMallocSafe(px * 3, "dist.frame_rgb");
     }
     if (want_rad && !d_frame_rad) {
-        d_stage_rad = (float*)hipMallocSafe(px * 3 * sizeof(float), "dist.stage_rad");
+        d_stage_rad = (float*)hipMallocSafe(stage_elems * sizeof(float), "dist.stage_rad");
         d_frame_rad = (float*)hipMallocSafe(px * 3 * sizeof(float), "dist.frame_rad");
     }
 }
 
+namespace {
+// An exception between ncclGroupStart and ncclGroupEnd (a Send / Recv that fails, an argument check) must not leave the
+// thread's group open: every later nccl call would be queued into it and never launched - a barrier that returns without
+// having synchronised, ranks that silently drift apart.  The guard closes the group on unwind (result ignored: the group is
+// being abandoned) and the caller marks the communicator failed.
+struct GroupGuard {
+    const Rccl& L; bool open = false;
+    explicit GroupGuard(const Rccl& l) : L(l) {}
+    void start() { PTMI_NCCL(L.GroupStart()); open = true; }
+    void end() { open = false; PTMI_NCCL(L.GroupEnd()); }
+    ~GroupGuard() { if (open) (void)L.GroupEnd(); }
+};
+}  // namespace
+
+void DistState::check() const {
+    if (!comm) throw ArgError("ptmi_dist_*: call ptmi_dist_init first");
+    if (failed) throw DistError("the communicator is in a failed state after an earlier RCCL error: ptmi_dist_finalize and ptmi_dist_init again");
+}
+
+int DistState::commCount() const {
+    check();
+    int n = 0;
+    PTMI_NCCL(rccl().CommCount((ncclComm_t)comm, &n));
+    return n;
+}
+
 void DistState::gatherFrame(const RenderState& r, int dst, int what) {
-    if (!comm) throw ArgError("ptmi_gather_frame: call ptmi_dist_init first");
+    check();
     if (dst < 0 || dst >= n_ranks) throw ArgError("ptmi_gather_frame: dst_rank out of range");
     if (!(what & 3) || (what & ~3)) throw ArgError("ptmi_gather_frame: what must be 1 (rgb8), 2 (radiance) or 3 (both)");
     if (!r.d_image) throw ArgError("ptmi_gather_frame: buffers not allocated");
@@ -185,20 +255,23 @@ void DistState::gatherFrame(const RenderState& r, int dst, int what) {
     const size_t n_mine = r.n_local * 3;
     if (rank == dst) ensureFrame(r.tile, want_rgb, want_rad);
     // the render stream has been synchronised by renderFrame(); a gather still in flight on this stream simply precedes us
-    PTMI_NCCL(L.GroupStart());
-    if (rank == dst) {
-        for (int k = 0; k < n_ranks; k++) {
-            if (k == dst) continue;
-            const size_t n_k = (size_t)countLocalRows(r.tile.height, n_ranks, k, r.tile.row_block) * (size_t)r.tile.width * 3;
-            if (!n_k) continue;
-            if (want_rgb) PTMI_NCCL(L.Recv(d_stage_rgb + h_tile_offset[k], n_k, ncclUint8, k, (ncclComm_t)comm, stream));
-            if (want_rad) PTMI_NCCL(L.Recv(d_stage_rad + h_tile_offset[k], n_k, ncclFloat32, k, (ncclComm_t)comm, stream));
+    try {
+        GroupGuard group(L);
+        group.start();
+        if (rank == dst) {
+            for (int k = 0; k < n_ranks; k++) {
+                if (k == dst) continue;
+                const size_t n_k = (size_t)countLocalRows(r.tile.height, n_ranks, k, r.tile.row_block) * (size_t)r.tile.width * 3;
+                if (!n_k) continue;
+                if (want_rgb) PTMI_NCCL(L.Recv(d_stage_rgb + h_tile_offset[k], n_k, ncclUint8, k, (ncclComm_t)comm, stream));
+                if (want_rad) PTMI_NCCL(L.Recv(d_stage_rad + h_tile_offset[k], n_k, ncclFloat32, k, (ncclComm_t)comm, stream));
+            }
+        } else if (n_mine) {
+            if (want_rgb) PTMI_NCCL(L.Send(r.d_image, n_mine, ncclUint8, dst, (ncclComm_t)comm, stream));
+            if (want_rad) PTMI_NCCL(L.Send(r.d_radiance, n_mine, ncclFloat32, dst, (ncclComm_t)comm, stream));
         }
-    } else if (n_mine) {
-        if (want_rgb) PTMI_NCCL(L.Send(r.d_image, n_mine, ncclUint8, dst, (ncclComm_t)comm, stream));
-        if (want_rad) PTMI_NCCL(L.Send(r.d_radiance, n_mine, ncclFloat32, dst, (ncclComm_t)comm, stream));
-    }
-    PTMI_NCCL(L.GroupEnd());
+        group.end();
+    } catch (const DistError&) { failed = true; throw; }
     if (rank == dst) {
         if (want_rgb) launch_place<unsigned char>(d_stage_rgb, r.d_image, rank, d_tile_offset, r.tile.width, r.tile.height, n_ranks, r.tile.row_block, d_frame_rgb, stream);
         if (want_rad) launch_place<float>(d_stage_rad, r.d_radiance, rank, d_tile_offset, r.tile.width, r.tile.height, n_ranks, r.tile.row_block, d_frame_rad, stream);
@@ -215,19 +288,22 @@ void DistState::wait() {
 }
 
 void DistState::barrier() {
-    if (!comm) throw ArgError("ptmi_dist_barrier: call ptmi_dist_init first");
-    PTMI_NCCL(rccl().AllReduce(d_token, d_token + 1, 1, ncclInt32, ncclSum, (ncclComm_t)comm, stream));
+    check();
+    try { PTMI_NCCL(rccl().AllReduce(d_token, d_token + 1, 1, ncclInt32, ncclSum, (ncclComm_t)comm, stream)); }
+    catch (const DistError&) { failed = true; throw; }
     PTMI_HIP(hipStreamSynchronize(stream));
     pending = false;
 }
 
 double DistState::allreduceMax(double v) {
-    if (!comm) throw ArgError("ptmi_dist_allreduce_max: call ptmi_dist_init first");
+    check();
     double* d = nullptr;
     PTMI_HIP(hipMalloc((void**)&d, 2 * sizeof(double)));
     struct Free { double* p; ~Free() { (void)hipFree(p); } } guard{d};
-    PTMI_HIP(hipMemcpy(d, &v, sizeof v, hipMemcpyHostToDevice));
-    PTMI_NCCL(rccl().AllReduce(d, d + 1, 1, ncclFloat64, ncclMax, (ncclComm_t)comm, stream));
+    const double init[2] = {v, v};                       // the result slot is never read uninitialised
+    PTMI_HIP(hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice));
+    try { PTMI_NCCL(rccl().AllReduce(d, d + 1, 1, ncclFloat64, ncclMax, (ncclComm_t)comm, stream)); }
+    catch (const DistError&) { failed = true; throw; }
     PTMI_HIP(hipStreamSynchronize(stream));
     PTMI_HIP(hipMemcpy(&v, d + 1, sizeof v, hipMemcpyDeviceToHost));
     return v;
@@ -238,29 +314,29 @@ void debugPlaceTiles(int width, int height, int n_ranks, int row_block, const un
                      unsigned char* out_rgb, float* out_rad, hipStream_t s) {
     if (width <= 0 || height <= 0 || n_ranks < 1 || row_block < 1) throw ArgError("bad geometry");
     const size_t n = (size_t)width * height * 3;
-    std::vector<long long> off((size_t)n_ranks);
-    long long acc = 0;
-    for (int k = 0; k < n_ranks; k++) { off[k] = acc; acc += (long long)countLocalRows(height, n_ranks, k, row_block) * width * 3; }
-    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_off, d_in, d_out;
+    std::vector<long long> off;
+    const size_t stage_elems = (size_t)tileOffsets(width, height, n_ranks, row_block, off);      // the staging layout of ptmi_gather_frame
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
+    Buf d_off;
     d_off.p = hipMallocSafe(off.size() * sizeof(long long), "place.off");
     PTMI_HIP(hipMemcpy(d_off.p, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
-    if (h_tiles_rgb && out_rgb) {
-        d_in.p = hipMallocSafe(n, "place.in"); d_out.p = hipMallocSafe(n, "place.out");
-        PTMI_HIP(hipMemcpy(d_in.p, h_tiles_rgb, n, hipMemcpyHostToDevice));
-        launch_place<unsigned char>((const unsigned char*)d_in.p, nullptr, -1, (const long long*)d_off.p, width, height, n_ranks, row_block, (unsigned char*)d_out.p, s);
+    auto run = [&](auto* h_in, auto* h_out) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(h_out)>>;
+        Buf d_in, d_out;
+        d_in.p = hipMallocSafe(stage_elems * sizeof(T), "place.in"); d_out.p = hipMallocSafe(n * sizeof(T), "place.out");
+        size_t src = 0;
+        for (int k = 0; k < n_ranks; k++) {                  // the caller's tiles are packed; the staging buffer's start on 16 elements
+            const size_t n_k = (size_t)countLocalRows(height, n_ranks, k, row_block) * (size_t)width * 3;
+            if (n_k) PTMI_HIP(hipMemcpy((T*)d_in.p + off[k], h_in + src, n_k * sizeof(T), hipMemcpyHostToDevice));
+            src += n_k;
+        }
+        launch_place<T>((const T*)d_in.p, nullptr, -1, (const long long*)d_off.p, width, height, n_ranks, row_block, (T*)d_out.p, s);
         PTMI_HIP(hipGetLastError());
         PTMI_HIP(hipStreamSynchronize(s));
-        PTMI_HIP(hipMemcpy(out_rgb, d_out.p, n, hipMemcpyDeviceToHost));
-        (void)hipFree(d_in.p); (void)hipFree(d_out.p); d_in.p = d_out.p = nullptr;
-    }
-    if (h_tiles_rad && out_rad) {
-        d_in.p = hipMallocSafe(n * sizeof(float), "place.in"); d_out.p = hipMallocSafe(n * sizeof(float), "place.out");
-        PTMI_HIP(hipMemcpy(d_in.p, h_tiles_rad, n * sizeof(float), hipMemcpyHostToDevice));
-        launch_place<float>((const float*)d_in.p, nullptr, -1, (const long long*)d_off.p, width, height, n_ranks, row_block, (float*)d_out.p, s);
-        PTMI_HIP(hipGetLastError());
-        PTMI_HIP(hipStreamSynchronize(s));
-        PTMI_HIP(hipMemcpy(out_rad, d_out.p, n * sizeof(float), hipMemcpyDeviceToHost));
-    }
+        PTMI_HIP(hipMemcpy(h_out, d_out.p, n * sizeof(T), hipMemcpyDeviceToHost));
+    };
+    if (h_tiles_rgb && out_rgb) run(h_tiles_rgb, out_rgb);
+    if (h_tiles_rad && out_rad) run(h_tiles_rad, out_rad);
 }
 
 }  // namespace ptmi

@@ -750,7 +750,9 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         }
         fp.n_frames = n_frames; fp.sample_mask = 0xffffu; fp.frame_color = r.d_frame_color; fp.n_local = (int)r.n_local;
     }
-    r.batch_frames = n_frames; r.batch_spp = g.config.spp;
+    // what ptmi_select_frame may resolve: nothing until THIS path-tracing run has completed (a Radiosity frame or a run that
+    // threw leaves the colour sums of some earlier run behind, and resolving those would overwrite a valid image)
+    r.batch_frames = 1; r.batch_spp = 0;
 
     const int n_local = (int)r.n_local;
     // segments per launch: 32 while the device has more waves to run than it holds at once; once the pixels still active fit
@@ -917,6 +919,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     PTMI_HIP(hipStreamSynchronize(s));                 // cudaDeviceSynchronize, application.h:199
     PTMI_HIP(hipGetLastError());
     drain.armed = false;
+    r.batch_frames = n_frames; r.batch_spp = g.config.spp;
 
     if (stats) {
         float ms = 0.0f;

@@ -195,6 +195,7 @@ struct DistState {
     hipStream_t stream = nullptr;
     hipEvent_t gather_done = nullptr;
     bool pending = false;                            // a gather has been enqueued and not waited for
+    bool failed = false;                             // an nccl* call failed: every later ptmi_dist_* call reports it until re-initialised
     int* d_token = nullptr;                          // barrier payload
     // destination side, (re)allocated per frame geometry
     unsigned char *d_stage_rgb = nullptr, *d_frame_rgb = nullptr;
@@ -209,6 +210,8 @@ struct DistState {
     void wait();
     void barrier();                                  // all ranks (1-int all-reduce + stream sync)
     double allreduceMax(double v);
+    int commCount() const;                           // ncclCommCount: the ranks RCCL itself reports
+    void check() const;                              // throws unless initialised and healthy
     void finalize();
     ~DistState() { finalize(); }
 private:

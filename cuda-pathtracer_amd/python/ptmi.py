@@ -28,7 +28,7 @@ EXPORTS = [
     "ptmi_host_cdf_record_layout", "ptmi_host_image",
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
     "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
-    "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect", "ptmi_host_fast_tree_stats",
+    "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_dist_comm_count", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect", "ptmi_host_fast_tree_stats",
 ]
 
 
@@ -139,6 +139,7 @@ def lib():
         L.ptmi_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.ptmi_read_frame.argtypes = [vp, vp, vp]
         L.ptmi_dist_barrier.argtypes = [vp]
+        L.ptmi_dist_comm_count.argtypes = [vp, ip]
         L.ptmi_dist_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
         L.ptmi_debug_set_packed_min_nodes.argtypes = [vp, C.c_int, ip]
         L.ptmi_debug_set_packed_top.argtypes = [vp, C.c_int, ip, ip]
@@ -472,6 +473,9 @@ class Renderer:
         rad = np.zeros((self.height, self.width, 3), np.float32) if radiance else None
         self._ck(self.L.ptmi_read_frame(self.h, rgb.ctypes.data if rgb8 else None, rad.ctypes.data if radiance else None))
         return rgb, rad
+
+    def dist_comm_count(self):
+        n = C.c_int(); self._ck(self.L.ptmi_dist_comm_count(self.h, C.byref(n))); return n.value
 
     def dist_barrier(self):
         self._ck(self.L.ptmi_dist_barrier(self.h))

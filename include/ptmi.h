@@ -262,7 +262,12 @@ int ptmi_host_image(const ptmi_ctx*, const unsigned char** rgb8, uint64_t* n_byt
 #define PTMI_GATHER_RGB8     1     /* the reference's output, 3 B/pixel */
 #define PTMI_GATHER_RADIANCE 2     /* float mean radiance, 12 B/pixel */
 int ptmi_dist_unique_id(void* out_id /* PTMI_UNIQUE_ID_BYTES */);
+/* Between processes RCCL needs dmabuf IPC on this driver stack: export HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every
+ * rank BEFORE anything in the process initialises HIP (the library does not set it for you).
+ * After an nccl* call has failed the communicator is marked failed: every later ptmi_dist_* / ptmi_gather_frame call returns
+ * PTMI_E_DIST until ptmi_dist_finalize + ptmi_dist_init. */
 int ptmi_dist_init(ptmi_ctx*, const void* id /* PTMI_UNIQUE_ID_BYTES */, int n_ranks, int rank);
+int ptmi_dist_comm_count(ptmi_ctx*, int* n_ranks);       /* ncclCommCount: the ranks RCCL itself reports for this communicator */
 int ptmi_dist_finalize(ptmi_ctx*);                       /* also done by ptmi_ctx_destroy */
 int ptmi_gather_frame(ptmi_ctx*, int dst_rank, int what /* PTMI_GATHER_RGB8 | PTMI_GATHER_RADIANCE */);
 int ptmi_gather_wait(ptmi_ctx*);

@@ -65,6 +65,48 @@ def test_gather_frame_with_several_ranks_over_a_mock_transport(tmp_path, world, 
     assert "mock-rccl-gather OK" in outs[dst][0]
 
 
+def _mock_env(tmp_path, **extra):
+    lib_dir = tmp_path / "lib"; lib_dir.mkdir()
+    wire = tmp_path / "wire"; wire.mkdir()
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
+                    os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
+    return dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire),
+                LD_LIBRARY_PATH=str(lib_dir) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), **extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,W,H,row_block,dst,what", [(2, 96, 70, 2, 0, 3), (3, 64, 48, 8, 1, 1)])
+def test_frames_survive_an_asynchronous_exchange(tmp_path, world, W, H, row_block, dst, what):
+    """The stand-in transport is asynchronous and stream-ordered like RCCL (tests/mock_rccl.cpp) and here delays every transfer
+    by 300 ms: frame k is gathered while frame k + 1 (another camera) is already being rendered, nothing is waited for in
+    between, two gathers queue up on the exchange stream.  What keeps frame k intact is the product's own ordering: the
+    resolve of frame k + 1 waits on the device for the gather that still reads the tile (checked once by hand with that wait
+    compiled out: frame 0 then arrives with frame 1's rows and this test fails - DESIGN.md 6)."""
+    env = _mock_env(tmp_path, PTMI_MOCK_RCCL_DELAY_MS="300")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_mock_worker.py"), str(W), str(H), "3", str(row_block), str(world), str(k),
+                               str(dst), str(what), str(tmp_path / "id.bin"), "async"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}: " + outs[k][0][-1500:] + outs[k][1][-1500:]
+    assert "mock-rccl-async OK" in outs[dst][0]
+
+
+@pytest.mark.gpu
+def test_a_failed_exchange_is_reported_and_poisons_the_communicator(tmp_path):
+    """An nccl call that fails between ncclGroupStart and ncclGroupEnd (the stand-in's ncclRecv, by injection): the error comes
+    back as PTMI_E_DIST, the abandoned group is closed, and every later ptmi_dist_* call fails too instead of queueing into a
+    dead group and returning as if it had synchronised."""
+    env = _mock_env(tmp_path, PTMI_MOCK_RCCL_FAIL="recv")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_mock_worker.py"), "48", "32", "2", "4", "2", str(k), "0", "3",
+                               str(tmp_path / "id.bin"), "fail"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}: " + outs[k][0][-1500:] + outs[k][1][-1500:]
+    assert "mock-rccl-fail OK" in outs[0][0]
+
+
 @pytest.mark.gpu
 def test_bench_with_three_ranks_over_the_mock_transport(tmp_path):
     """bench.py --gpus 3 exactly as the driver launches it (torch.distributed.run, one process per rank), the frame exchange

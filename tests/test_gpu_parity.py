@@ -387,6 +387,27 @@ def test_frame_batch_equals_successive_frames(R, name, sub, W, H, spp, depth, n)
         R.set_config(spp=1, segments_per_launch=0); R.set_packed_min_nodes(8192)
 
 
+def test_select_frame_after_a_radiosity_frame_is_rejected(R):
+    """ptmi_select_frame resolves the colour sums of the last path-tracing run.  After a Radiosity-integrator frame (or a run
+    that failed) those sums belong to some earlier frame: the call must return PTMI_E_INVALID and leave the image alone."""
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path); R.update_resolution(48, 40)
+    try:
+        R.set_config(spp=4, max_depth=5, integrator=0)
+        R.render_frame()
+        R.select_frame(0)                                           # fine after a path-tracing frame
+        R.set_config(integrator=1)
+        R.render_frame()
+        rgb, rad = R.read_image()
+        with pytest.raises(ptmi.PtmiError) as e:
+            R.select_frame(0)
+        assert e.value.code == -1
+        rgb2, rad2 = R.read_image()
+        assert (rgb == rgb2).all() and (bits(rad) == bits(rad2)).all()
+    finally:
+        R.set_config(integrator=0, spp=1)
+
+
 @pytest.mark.parametrize("name,sub", [("05_instances.pbrt", 0), ("03_arealight.pbrt", 1), ("04_materials.pbrt", 0)])
 def test_pbrt_scene_renders_like_the_oracle_on_the_same_primitives(R, name, sub):
     """ptmi_load_scene on a .pbrt file (own parser, pinned against the compiled reference importer in
