@@ -33,6 +33,51 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver stack
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the launcher.
+    It starts N fresh children - one per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment,
+    exactly what torch.distributed.run would give them - relays rank 0's JSON line and exits with the worst child's code.
+    Runs before torch or the library is imported: the launcher never touches a GPU, and no process that has is re-executed."""
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args()[0].gpus
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None))
+    import threading
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line); sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True); t.start()
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for k in sorted(alive):
+            rc = procs[k].poll()
+            if rc is None:
+                continue
+            alive.discard(k)
+            if rc != 0:
+                worst = max(worst, rc if rc > 0 else 1)
+                for j in alive:                          # a rank died: the others would wait at the rendezvous for ever
+                    procs[j].terminate()
+        time.sleep(0.05)
+    t.join(timeout=5)
+    sys.exit(worst)
+
+
+if __name__ == "__main__":
+    _self_launch()
 sys.path.insert(0, os.path.join(ROOT, "cuda-pathtracer_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -70,6 +115,10 @@ CONFIGS = {
                          served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
+    "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
+                     served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp"),
+    "c5strong_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
+                          served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp through the opt-in fast tree"),
     "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
                served_from="l2/mall/hbm", what="BASELINE configs[4]"),
 }
@@ -289,9 +338,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
     if world != n_gpus:
-        if world == 1 and n_gpus > 1:
-            raise SystemExit(f"--gpus {n_gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr 127.0.0.1 bench.py ...")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {n_gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
@@ -310,7 +356,7 @@ def main():
 
     name = args.config
     cfg = dict(CONFIGS[name])
-    strong = name in ("c4", "c5")
+    strong = name in ("c4", "c5", "c5strong", "c5strong_fast")
     if name == "c2" and world > 1:                    # weak scaling of the headline configuration
         cfg["width"] = cfg["height"] = int(round(1024 * math.sqrt(n_gpus)))
     if args.side:
@@ -475,7 +521,41 @@ def main():
         r.set_config(fast_tree=False)
         out["extra_configs"] = extras
 
+    # N > 1, default line: `value` stays the weak-scaled headline configuration; BASELINE's own multi-GPU configurations are
+    # timed in the same run as STRONG scaling (fixed frame, rows tiled over the N ranks, one RCCL gather per frame): configs[3]
+    # (c4, at its full 512 spp) and configs[4] (c5, the 1 M-triangle frame at 64 of its 2048 spp, through the reference's tree
+    # and through the opt-in fast tree).  A failure here is recorded in the line and does not cost the headline number.
+    if world > 1 and name == "c2" and not args.no_extra and not args.side and not args.spp:
+        extras = []
+        loaded = cfg["scene"]
+        for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_fast", 3)):
+            try:
+                xcfg = dict(CONFIGS[xname])
+                if args.rehearse_gloo or args.rehearse_shared_gpu:     # rehearsal on one shared GPU: same control flow, small frames
+                    xcfg.update(width=256, height=256, spp=4)
+                if xcfg["scene"] != loaded:
+                    load_scene(r, xcfg["scene"] if not (shared and xcfg["scene"] == "tess1m") else "cbox.obj"); loaded = xcfg["scene"]
+                r.update_resolution(xcfg["width"], xcfg["height"], n_ranks=world, rank=rank, row_block=8)
+                if fg is not None:
+                    fg = ptmi_dist.FrameGather(dist, xcfg["width"], xcfg["height"], world, rank, 8, torch.device("cpu"))
+                xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
+                xsamples = float(xcfg["width"]) * xcfg["height"] * xcfg["spp"] * xsteps
+                if rank == 0:
+                    extras.append({"name": xname, "scaling": "strong", "workload": f"{xcfg['scene']} {xcfg['width']}x{xcfg['height']}, {xcfg['spp']} spp, max_depth "
+                                   f"{xcfg['max_depth']}, rows tiled over {world} GPUs in interleaved 8-row blocks + 1 RCCL gather ({args.gather}) per frame ({xcfg['what']})",
+                                   "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": xsteps, "warmup": 1,
+                                   "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"]})
+            except Exception as e:                       # noqa: BLE001 - recorded, the run goes on
+                if rank == 0:
+                    extras.append({"name": xname, "error": f"{type(e).__name__}: {e}"})
+                break                                     # ranks must stay in step: nobody goes on after a failure
+        r.set_config(fast_tree=False)
+        if rank == 0:
+            out["extra_configs"] = extras
+
     if rank == 0:
+        if rccl:
+            out["rccl_ranks"] = r.dist_comm_count()       # what RCCL itself reports for the communicator the gathers ran on (ncclCommCount)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, cfg["width"], cfg["height"])
         print(json.dumps(out), flush=True)

@@ -910,7 +910,9 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         PTMI_HIP(hipStreamWaitEvent(s, ev, 0));
     }
     const size_t after_pairs = n_ev;
+#ifndef PTMI_EXPERIMENT_NO_RESOLVE_GATE      // (never defined in the shipped build: make ab-host-lib, to see the asynchronous-exchange test fail without it)
     if (r.resolve_gate) PTMI_HIP(hipStreamWaitEvent(s, r.resolve_gate, 0));   // a gather of the previous frame may still read the tile
+#endif
     launch_resolve(r.tile, r.d_state, g.config.spp, r.d_image, r.d_radiance, s);
     const hipEvent_t ev_end = event(n_ev++);
     PTMI_HIP(hipEventRecord(ev_end, s));

@@ -28,6 +28,8 @@ from oracle_binding import OracleScene, SCENES, default_camera  # noqa: E402
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("PTMI_WORKER_DEADLINE_S", "240")), exit=True)      # a hung exchange ends with a traceback, not a silent timeout
     W, H, spp, row_block, world, rank, dst, what = (int(a) for a in sys.argv[1:9])
     id_file = sys.argv[9]
     mode = sys.argv[10] if len(sys.argv) > 10 else ""

@@ -6,16 +6,23 @@
 // ptmi_gather_frame with its exact tile sizes and offsets, the placement kernel, barrier and max-reduction - with several
 // processes on ONE GPU.  Only the wire is mocked.
 //
-// STREAM-ORDERED AND ASYNCHRONOUS, like the real library: ncclGroupEnd (or a bare ncclSend / ncclRecv) returns at once.  What
-// it leaves on the caller's stream is (1) an event marking everything enqueued before the group and (2) a one-wave GATE kernel
-// that holds the stream until a flag in host memory is set.  A worker thread - one per process, batches strictly in posting
-// order - waits for the event, moves the bytes (device -> file for a send, file -> device for a receive, on a stream of its
-// own) and then opens the gate: whatever the caller enqueues behind the group (the placement kernel, the gather_done event
-// the next frame's resolve waits for) runs after the data has moved, whatever the caller enqueues on OTHER streams meanwhile
-// runs concurrently - so the product's own ordering (resolve_gate, two gathers queued on one stream, staging-buffer reuse) is
-// what keeps a frame intact, not a blocking call.  PTMI_MOCK_RCCL_DELAY_MS delays every batch in the worker (makes the window
-// in which a missing dependency would corrupt a tile seconds wide); PTMI_MOCK_RCCL_FAIL=recv|send makes that call return
-// ncclInvalidArgument (fault injection for the product's error path).  The gate gives up after 120 s.
+// STREAM-ORDERED AND ASYNCHRONOUS, like the real library: ncclGroupEnd (or a bare ncclSend / ncclRecv) returns at once and
+// leaves on the caller's stream, in this order:
+//   [delay kernel]  PTMI_MOCK_RCCL_DELAY_MS of device-side spinning: makes the window in which a missing dependency would
+//                   corrupt a tile that wide (nothing on the host is waited for here)
+//   [copy kernels]  every send buffer -> a pinned host staging buffer; an event behind them tells the worker thread when
+//   [gate kernel]   (only with receives) one wave that holds the stream until the worker has put the peers' bytes into the
+//                   receives' pinned staging buffers and set a flag in host memory; gives up after 120 s
+//   [copy kernels]  staging -> every receive buffer
+// so whatever the caller enqueues behind the group (the placement kernel, the gather_done event the next frame's resolve
+// waits for) runs after the data has moved, and whatever it enqueues on OTHER streams meanwhile runs concurrently: the
+// product's own ordering (resolve_gate, two gathers queued on one stream, staging-buffer reuse) is what keeps a frame intact,
+// not a blocking call.  The worker thread - one per process, batches strictly in posting order - makes NO call that needs a
+// GPU queue (HIP multiplexes a process's streams onto a few hardware queues; a copy of the worker's queued behind the gate it
+// is meant to open would never run): it waits for the event, writes the sends' files, reads the receives' files, sets the flag.
+// Run the processes with GPU_MAX_HW_QUEUES=8 so that the exchange stream does not share a hardware queue with a render
+// stream (sharing only delays, but it would also hide the very race the asynchronous test is there to catch).
+// PTMI_MOCK_RCCL_FAIL=recv|send makes that call return ncclInvalidArgument (fault injection for the product's error path).
 //
 // Build (the tests do it): hipcc -shared -fPIC -o <dir>/librccl.so.1 tests/mock_rccl.cpp
 // The directory for the files comes from PTMI_MOCK_RCCL_DIR.
@@ -39,14 +46,16 @@
 
 namespace {
 struct Comm { std::string dir; int n = 0, rank = 0; std::vector<unsigned long long> sent, received; unsigned long long reductions = 0; };
-struct Op { bool send; void* buf; size_t bytes; int peer; Comm* comm; hipStream_t stream; unsigned long long seq; };
-struct Batch { std::vector<Op> ops; hipEvent_t ready; int* flag; int device; };      // flag: host-mapped, 0 = closed, 1 = open, 2 = failed
+struct Op { bool send; void* buf; size_t bytes; int peer; Comm* comm; hipStream_t stream; unsigned long long seq; char* staging; };   // staging: pinned host, mapped
+struct Batch { std::vector<Op> ops; hipEvent_t copied; int* flag; };      // flag: host-mapped (nullptr without receives), 0 = closed, 1 = open, 2 = failed
 thread_local std::vector<Op> g_ops;
 thread_local int g_depth = 0;
 
-std::mutex g_mu;
-std::condition_variable g_cv;
-std::deque<Batch> g_queue;
+// never destroyed: the worker thread is detached and waits on g_cv for the life of the process; destroying a condition
+// variable that has a waiter (a static destructor at exit would) blocks in pthread_cond_destroy for ever
+std::mutex& g_mu = *new std::mutex;
+std::condition_variable& g_cv = *new std::condition_variable;
+std::deque<Batch>& g_queue = *new std::deque<Batch>;
 bool g_worker_started = false;
 std::atomic<int> g_in_flight{0};
 std::atomic<int> g_failed{0};
@@ -89,33 +98,15 @@ __global__ void mock_gate(volatile int* flag) {
         __builtin_amdgcn_s_sleep(64);
     }
 }
-
-bool moveBatch(const Batch& b, hipStream_t s) {
-    std::vector<char> host;
-    for (const Op& op : b.ops) {                                   // all sends first: a rank that both sends and receives cannot block itself
-        if (!op.send) continue;
-        host.resize(op.bytes);
-        if (op.bytes && (hipMemcpyAsync(host.data(), op.buf, op.bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return false;
-        Comm& c = *op.comm;
-        writeFile(c.dir + "/msg_" + std::to_string(c.rank) + "_" + std::to_string(op.peer) + "_" + std::to_string(op.seq), host.data(), op.bytes);
-    }
-    for (const Op& op : b.ops) {
-        if (op.send) continue;
-        host.resize(op.bytes);
-        Comm& c = *op.comm;
-        const std::string path = c.dir + "/msg_" + std::to_string(op.peer) + "_" + std::to_string(c.rank) + "_" + std::to_string(op.seq);
-        if (!readFile(path, host.data(), op.bytes)) return false;            // also: the sender posted another size
-        struct stat st; if (stat(path.c_str(), &st) != 0 || (size_t)st.st_size != op.bytes) return false;
-        std::remove(path.c_str());
-        if (op.bytes && (hipMemcpyAsync(op.buf, host.data(), op.bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return false;
-    }
-    return true;
+__global__ void mock_delay(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+__global__ void mock_copy(const char* __restrict__ src, char* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 void worker() {
-    const char* d = std::getenv("PTMI_MOCK_RCCL_DELAY_MS");
-    const int delay_ms = d ? std::atoi(d) : 0;
-    hipStream_t s = nullptr; int dev = -1;
     for (;;) {
         Batch b;
         {
@@ -123,35 +114,56 @@ void worker() {
             g_cv.wait(lk, [] { return !g_queue.empty(); });
             b = std::move(g_queue.front()); g_queue.pop_front();
         }
-        if (b.device != dev) { (void)hipSetDevice(b.device); dev = b.device; if (s) (void)hipStreamDestroy(s); s = nullptr; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
-        bool ok = hipEventSynchronize(b.ready) == hipSuccess;      // everything the caller had enqueued before the group
-        if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
-        ok = ok && moveBatch(b, s);
+        bool ok = hipEventSynchronize(b.copied) == hipSuccess;    // the sends' bytes are in their staging buffers (a host-side wait)
+        for (const Op& op : b.ops) {                                // all sends first: a rank that both sends and receives cannot block itself
+            if (!op.send || !ok) continue;
+            Comm& c = *op.comm;
+            writeFile(c.dir + "/msg_" + std::to_string(c.rank) + "_" + std::to_string(op.peer) + "_" + std::to_string(op.seq), op.staging, op.bytes);
+        }
+        for (const Op& op : b.ops) {
+            if (op.send || !ok) continue;
+            Comm& c = *op.comm;
+            const std::string path = c.dir + "/msg_" + std::to_string(op.peer) + "_" + std::to_string(c.rank) + "_" + std::to_string(op.seq);
+            struct stat st;
+            ok = readFile(path, op.staging, op.bytes) && stat(path.c_str(), &st) == 0 && (size_t)st.st_size == op.bytes;   // also: the sender posted another size
+            std::remove(path.c_str());
+        }
         if (!ok) g_failed.store(1);
-        __atomic_store_n(b.flag, ok ? 1 : 2, __ATOMIC_RELEASE);   // opens the gate
-        (void)hipEventDestroy(b.ready);
+        if (b.flag) __atomic_store_n(b.flag, ok ? 1 : 2, __ATOMIC_RELEASE);   // opens the gate
         g_in_flight.fetch_sub(1);
     }
 }
 
-// posts the thread's pending ops as one batch: event + gate on every stream involved (the product uses one), then returns
+// posts the thread's pending ops as one batch (see the head of this file), then returns
 ncclResult_t post() {
     std::vector<Op> ops; ops.swap(g_ops);
     if (ops.empty()) return ncclSuccess;
     if (g_failed.load()) return ncclSystemError;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return ncclUnhandledCudaError;
     const hipStream_t s = ops[0].stream;
     for (const Op& op : ops) if (op.stream != s) return ncclInvalidUsage;       // one stream per group is all this stand-in does
-    Batch b; b.ops = std::move(ops); b.device = device;
-    if (hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipHostMalloc((void**)&b.flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return ncclUnhandledCudaError;   // leaked on purpose: tiny, and the gate may still be reading it
-    *b.flag = 0;
-    int* d_flag = nullptr;
-    if (hipHostGetDevicePointer((void**)&d_flag, b.flag, 0) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipEventRecord(b.ready, s) != hipSuccess) return ncclUnhandledCudaError;
-    hipLaunchKernelGGL(mock_gate, dim3(1), dim3(1), 0, s, (volatile int*)d_flag);
+    const char* d = std::getenv("PTMI_MOCK_RCCL_DELAY_MS");
+    const int delay_ms = d ? std::atoi(d) : 0;
+    Batch b; b.flag = nullptr;
+    bool any_recv = false;
+    auto dev = [](void* host) { void* p = nullptr; return hipHostGetDevicePointer(&p, host, 0) == hipSuccess ? (char*)p : (char*)nullptr; };
+    // pinned buffers are never freed (hipHostFree may wait for the device; these are test-sized and the process is short-lived)
+    for (Op& op : ops) {
+        if (hipHostMalloc((void**)&op.staging, op.bytes ? op.bytes : 1, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return ncclUnhandledCudaError;
+        any_recv = any_recv || !op.send;
+    }
+    if (delay_ms > 0) hipLaunchKernelGGL(mock_delay, dim3(1), dim3(1), 0, s, (unsigned long long)delay_ms * 100000ull);
+    for (const Op& op : ops)
+        if (op.send && op.bytes) hipLaunchKernelGGL(mock_copy, dim3(64), dim3(256), 0, s, (const char*)op.buf, dev(op.staging), op.bytes);
+    if (hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess || hipEventRecord(b.copied, s) != hipSuccess) return ncclUnhandledCudaError;
+    if (any_recv) {
+        if (hipHostMalloc((void**)&b.flag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return ncclUnhandledCudaError;
+        *b.flag = 0;
+        hipLaunchKernelGGL(mock_gate, dim3(1), dim3(1), 0, s, (volatile int*)dev(b.flag));
+        for (const Op& op : ops)
+            if (!op.send && op.bytes) hipLaunchKernelGGL(mock_copy, dim3(64), dim3(256), 0, s, (const char*)dev(op.staging), (char*)op.buf, op.bytes);
+    }
     if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
+    b.ops = std::move(ops);
     g_in_flight.fetch_add(1);
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -194,13 +206,13 @@ ncclResult_t ncclGroupEnd() { if (--g_depth > 0) return ncclSuccess; g_depth = 0
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s) {
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (peer < 0 || peer >= c->n || peer == c->rank || failInjected("send")) return ncclInvalidArgument;
-    g_ops.push_back(Op{true, const_cast<void*>(buf), count * typeSize(t), peer, c, s, c->sent[peer]++});
+    g_ops.push_back(Op{true, const_cast<void*>(buf), count * typeSize(t), peer, c, s, c->sent[peer]++, nullptr});
     return g_depth ? ncclSuccess : post();
 }
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s) {
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (peer < 0 || peer >= c->n || peer == c->rank || failInjected("recv")) return ncclInvalidArgument;
-    g_ops.push_back(Op{false, buf, count * typeSize(t), peer, c, s, c->received[peer]++});
+    g_ops.push_back(Op{false, buf, count * typeSize(t), peer, c, s, c->received[peer]++, nullptr});
     return g_depth ? ncclSuccess : post();
 }
 // the reductions stay host-synchronous (the product follows each with a stream synchronisation anyway): the stream is drained

@@ -54,7 +54,7 @@ def test_gather_frame_with_several_ranks_over_a_mock_transport(tmp_path, world, 
     hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
                     os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
-    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire),
+    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire), GPU_MAX_HW_QUEUES="8",
                LD_LIBRARY_PATH=str(lib_dir) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_mock_worker.py"), str(W), str(H), "3", str(row_block), str(world), str(k),
                                str(dst), str(what), str(tmp_path / "id.bin")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -71,7 +71,8 @@ def _mock_env(tmp_path, **extra):
     hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
                     os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
-    return dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire),
+    # GPU_MAX_HW_QUEUES=8: every stream of a rank on a hardware queue of its own (tests/mock_rccl.cpp says why)
+    return dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire), GPU_MAX_HW_QUEUES="8",
                 LD_LIBRARY_PATH=str(lib_dir) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), **extra)
 
 
@@ -119,7 +120,7 @@ def test_bench_with_three_ranks_over_the_mock_transport(tmp_path):
     hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-o", str(lib_dir / "librccl.so.1"),
                     os.path.join(HERE, "mock_rccl.cpp")], check=True, timeout=600)
-    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire), PTMI_RCCL_LIB=str(lib_dir / "librccl.so.1"))
+    env = dict(os.environ, OMP_NUM_THREADS="2", PTMI_MOCK_RCCL_DIR=str(wire), PTMI_RCCL_LIB=str(lib_dir / "librccl.so.1"), GPU_MAX_HW_QUEUES="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1",
            "--rehearse-shared-gpu", "--no-cpu", "--spp", "4", "--side", "192"]
@@ -210,3 +211,27 @@ def test_bench_line_carries_every_contract_field():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 3` with NO launcher around it (WORLD_SIZE unset), as the driver may run it: bench.py starts the three
+    ranks itself before anything touches a GPU, relays rank 0's line and exits with the worst child's code.  Default N > 1 line:
+    weak-scaled c2 as `value` plus the strong-scaled BASELINE configurations (c4, c5 through both trees; shrunk here by the
+    rehearsal switch) and the rank count RCCL itself reports.  The ranks share the test box's GPU over tests/mock_rccl.cpp."""
+    import json
+    root = os.path.dirname(HERE)
+    env = _mock_env(tmp_path)
+    env["PTMI_RCCL_LIB"] = str(tmp_path / "lib" / "librccl.so.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--rehearse-shared-gpu", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["scaling"] == "weak" and line["value"] > 0 and line["rccl_ranks"] == 3
+    extras = {e["name"]: e for e in line["extra_configs"]}
+    assert set(extras) == {"c4", "c5strong", "c5strong_fast"} and all("error" not in e and e["value"] > 0 and e["scaling"] == "strong" for e in extras.values()), extras
+    # a rank that fails must fail the whole run: an unknown flag makes every child exit non-zero
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
