@@ -211,21 +211,16 @@ void SceneState::freePacked() {
     d_scene.load_index = nullptr; d_scene.n_top = 0; d_scene.top_depth = 0;
 }
 
-// The packed layout of csrc/device_scene.h: same tree, same visiting order, records placed so that a ray touches fewer lines.
-void SceneState::buildPacked() {
-    freePacked();
-    const int n = (int)bvh_nodes.size(), n_prims = (int)h_primitives.size();
-    if (!d_nodes || d_scene.lds_resident || bvh_depth > 62 || n < packed_min_nodes || n_prims >= (1 << 28)) return;
-    for (const BVHNode& b : bvh_nodes) if (b.isLeaf() && b.prim_count > 7) return;      // the leaf record packs count into 3 bits
+// The node records of the packed layout (csrc/device_scene.h: PACKED LAYOUT): same tree, same visiting order, explicit links,
+// sibling pairs adjacent, the nodes of depth <= D first (level by level) while they fit top_records positions.  false: a leaf
+// holds more than 7 primitives (its count has 3 bits).
+bool packBvhNodes(const std::vector<BVHNode>& bvh_nodes, int top_records, std::vector<float4>& g, int& n_pos_out, int& n_top_out, int& top_depth_out) {
+    const int n = (int)bvh_nodes.size();
+    for (const BVHNode& b : bvh_nodes) if (b.isLeaf() && b.prim_count > 7) return false;
     auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
     std::vector<int> pos((size_t)n, -1), subtree((size_t)n, 1), stack;
     for (int i = n; i-- > 0;)
         if (!bvh_nodes[i].isLeaf()) subtree[i] = 1 + subtree[bvh_nodes[i].left_child] + subtree[bvh_nodes[i].right_child];
-    // positions: the nodes of depth <= D first, level by level (sibling pairs adjacent: the top that ptmi_bounce_phased keeps in
-    // LDS is simply "position < n_top"), then every remaining pair in pre-order of its parent
-    std::vector<int> depth((size_t)n, 0);
-    for (int i = 0; i < n; i++)
-        if (!bvh_nodes[i].isLeaf()) { depth[bvh_nodes[i].left_child] = depth[i] + 1; depth[bvh_nodes[i].right_child] = depth[i] + 1; }
     int n_pos = 2, top_depth = -1;                     // root at 0, position 1 pads it to a pair
     pos[0] = 0;
     {
@@ -233,7 +228,7 @@ void SceneState::buildPacked() {
         for (int d = 0; !level.empty(); d++) {
             int pairs = 0;
             for (int x : level) if (!bvh_nodes[x].isLeaf()) pairs++;
-            if (n_pos + 2 * pairs > packed_top_records) break;           // the next level no longer fits the LDS top
+            if (n_pos + 2 * pairs > top_records) break;                   // the next level no longer fits the LDS top
             next_level.clear();
             for (int x : level) {
                 if (bvh_nodes[x].isLeaf()) continue;
@@ -245,7 +240,7 @@ void SceneState::buildPacked() {
             level.swap(next_level);
         }
     }
-    const int n_top = packed_top_records >= 2 ? n_pos : 0;
+    const int n_top = top_records >= 2 ? n_pos : 0;
     stack.push_back(0);
     while (!stack.empty()) {                           // the rest: pairs in pre-order of their parents
         const int x = stack.back(); stack.pop_back();
@@ -256,7 +251,7 @@ void SceneState::buildPacked() {
     }
     auto position_of = [&](int pre) { return pre >= n ? n_pos : pos[pre]; };
     const float inf = std::numeric_limits<float>::infinity();
-    std::vector<float4> g((size_t)2 * n_pos, make_float4(inf, inf, inf, 0.0f));
+    g.assign((size_t)2 * n_pos, make_float4(inf, inf, inf, 0.0f));
     g[2] = make_float4(inf, inf, inf, bits(0)); g[3] = make_float4(-inf, -inf, -inf, bits(~n_pos));   // padding: an empty leaf nobody links to
     for (int i = 0; i < n; i++) {
         const BVHNode& b = bvh_nodes[i];
@@ -266,6 +261,19 @@ void SceneState::buildPacked() {
         g[2 * (size_t)pos[i]] = make_float4(b.bbox.min.x, b.bbox.min.y, b.bbox.min.z, bits(a_));
         g[2 * (size_t)pos[i] + 1] = make_float4(b.bbox.max.x, b.bbox.max.y, b.bbox.max.z, bits(b_));
     }
+    n_pos_out = n_pos; n_top_out = n_top; top_depth_out = top_depth;
+    return true;
+}
+
+// The packed layout of csrc/device_scene.h: same tree, same visiting order, records placed so that a ray touches fewer lines.
+void SceneState::buildPacked() {
+    freePacked();
+    const int n = (int)bvh_nodes.size(), n_prims = (int)h_primitives.size();
+    if (!d_nodes || d_scene.lds_resident || bvh_depth > 62 || n < packed_min_nodes || n_prims >= (1 << 28)) return;
+    auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
+    std::vector<float4> g;
+    int n_pos = 0, n_top = 0, top_depth = -1;
+    if (!packBvhNodes(bvh_nodes, packed_top_records, g, n_pos, n_top, top_depth)) return;
     // materials: (normal, table row) per slot + the distinct (Kd, Ke) pairs; load-order index on its own
     std::map<std::array<uint32_t, 6>, int> rows;
     std::vector<float4> gm((size_t)n_prims), tab;
@@ -441,7 +449,6 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     d.grid = (unsigned int*)upload(nullptr, (size_t)n * kGridSize * sizeof(unsigned int), "d_radiosity_grid_counts");
     d.rad_grid = (float4*)upload(nullptr, (size_t)n * kGridSize * sizeof(float4), "d_radiosity_grids");
     d.rays = (unsigned long long*)upload(nullptr, sizeof(unsigned long long), "d_radiosity_rays");
-    PTMI_HIP(hipMemset(d.rays, 0, sizeof(unsigned long long)));
 
     RadiosityParams prm;
     prm.num_iterations = num_iterations; prm.mc_samples = mc_samples; prm.use_monte_carlo = use_monte_carlo ? 1 : 0;

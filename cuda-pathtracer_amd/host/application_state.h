@@ -250,6 +250,8 @@ void renderFrame(ApplicationState& g_state, FrameStats* stats);
 void renderFrames(ApplicationState& g_state, int n_frames, FrameStats* stats);
 void selectFrame(ApplicationState& g_state, int frame);
 
+bool packBvhNodes(const std::vector<BVHNode>& bvh_nodes, int top_records, std::vector<float4>& g, int& n_pos, int& n_top, int& top_depth);
+
 // GF(2) matrices T^(2^67 * 2^k), k = 0..31, of the xorwow state transition (cuRAND's subsequence skip-ahead).
 std::vector<uint32_t> buildXorwowJumpMatrices();
 
