@@ -13,8 +13,7 @@
 // restated too - header grammar, ASCII and both binary byte orders, every scalar type with rply's range checks, lists -
 // for what the import uses: vertex x/y/z (+ nx/ny/nz), the face list vertex_indices / vertex_index, triangles only.
 //
-// Not restated (the load fails with a message naming the construct): blackbody
-// area lights (DiffuseAreaLightBB::LinRGB, a CIE table integration), "spectrum" parameters read from .spd files, shape
+// Not restated (the load fails with a message naming the construct): "spectrum" parameters read from .spd files, shape
 // types the reference importer crashes on (it dereferences the null shape of every type but trianglemesh / plymesh / curve /
 // sphere / disk).  Rotate calls the host libm's sinf / cosf exactly as the library does (the numerics contract's sincos differs
 // from glibc's in the last bit on 2.6 % of angles, which would show in every rotated vertex).
@@ -61,6 +60,41 @@ inline M3 operator*(const M3& a, float b) { return m3(a.vx * b, a.vy * b, a.vz *
 inline M3 transpose3(const M3& a) { return m3(v3(a.vx.x, a.vy.x, a.vz.x), v3(a.vx.y, a.vy.y, a.vz.y), v3(a.vx.z, a.vy.z, a.vz.z)); }
 inline float determinant3(const M3& a) { return dot3(a.vx, cross3(a.vy, a.vz)); }
 inline M3 inverse_transpose3(const M3& a) { return m3(cross3(a.vy, a.vz), cross3(a.vz, a.vx), cross3(a.vx, a.vy)) * (1 / determinant3(a)); }
+// DiffuseAreaLightBB::LinRGB (impl/semantic/Lights.cpp:233-318): the colour of a blackbody of the given temperature - Planck's
+// law at 400, 401, ... 700 nm relative to its peak, through the analytic fits of the CIE 1931 matching functions (Wyman, Sloan,
+// Shirley 2013) and the XYZ -> linear sRGB matrix; float arithmetic in the library's order, powf / expf from the host libm as
+// there (the compiled reference importer returns the same bits: tests/test_pbrt_loader.py).
+inline float cie_fit(float lambda, const float (*lobe)[4], int n) {                 // lobe: {amplitude, centre, slope below, slope above}
+    float s = 0.0f;
+    for (int k = 0; k < n; k++) {
+        const float t = (lambda - lobe[k][1]) * ((lambda < lobe[k][1]) ? lobe[k][2] : lobe[k][3]);
+        const float term = lobe[k][0] * expf(-0.5f * t * t);
+        s = k == 0 ? term : s + term;
+    }
+    return s;
+}
+inline V3 blackbodyLinRGB(float temperature) {
+    static const float k = 1.3806488E-23f, h = 6.62606957E-34f, c = 2.99792458E8f;
+    static const float X[3][4] = {{0.362f, 442.0f, 0.0624f, 0.0374f}, {1.056f, 599.8f, 0.0264f, 0.0323f}, {-0.065f, 501.1f, 0.0490f, 0.0382f}};
+    static const float Y[2][4] = {{0.821f, 568.8f, 0.0213f, 0.0247f}, {0.286f, 530.9f, 0.0613f, 0.0322f}};
+    static const float Z[2][4] = {{1.217f, 437.0f, 0.0845f, 0.0278f}, {0.681f, 459.0f, 0.0385f, 0.0725f}};
+    auto bb = [temperature](float lambda) {
+        lambda *= 1E-3f;                                                           // nm to microns
+        return float(((2.0f * 1E24f * h * c * c) / powf(lambda, 5.0f)) * (1.0f / (expf((1E6f * h * c) / (lambda * k * temperature)) - 1.0f)));
+    };
+    const float lambda_max_radiance = 2.8977721e-3f / temperature * 1e9f;
+    const float max_radiance = bb(lambda_max_radiance);
+    float x = 0.0f, y = 0.0f, z = 0.0f, n = 0.0f;
+    for (float lambda = 400.0f; lambda <= 700.0f; lambda += 1.0f) {
+        const float p = bb(lambda) / max_radiance;
+        x += p * cie_fit(lambda, X, 3);
+        y += p * cie_fit(lambda, Y, 2);
+        z += p * cie_fit(lambda, Z, 2);
+        n += cie_fit(lambda, Y, 2);
+    }
+    return m3(v3(3.2404542f, -0.9692660f, 0.0556434f), v3(-1.5371385f, 1.8760108f, -0.2040259f), v3(-0.4985314f, 0.0415560f, 1.0572252f)) *
+           v3(x / n, y / n, z / n);
+}
 struct Affine { M3 l; V3 p; };
 inline Affine affine(const M3& l, V3 p) { Affine a; a.l = l; a.p = p; return a; }
 inline Affine operator*(const Affine& a, const Affine& b) { return affine(a.l * b.l, a.l * b.p + a.p); }
@@ -894,7 +928,10 @@ struct Semantic {
             if (a.type == "diffuse") {
                 if (a.hasNf("L", 2)) {
                     a.get1i("nsamples", 1);
-                    if (mesh) throw PbrtError("blackbody area lights (\"blackbody L\" [T scale]) are not supported by this loader");
+                    float TS[2]; a.get2f(TS, "L");
+                    // DiffuseAreaLightBB: loadPBRT takes light->LinRGB() (utils/pbrt_loader.h:311-312) - the temperature's colour,
+                    // normalised; the second float ("scale") is parsed and never used
+                    if (mesh) { mesh->hasLight = true; mesh->L = blackbodyLinRGB(TS[0]); }
                 } else if (a.hasNf("L", 3)) {
                     float L[3]; a.get3f(L, "L"); a.get1i("nsamples", 1);
                     if (mesh) { mesh->hasLight = true; mesh->L = v3(L[0], L[1], L[2]); }

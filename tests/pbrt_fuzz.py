@@ -161,7 +161,8 @@ def random_scene(seed):
         elif r < 0.55: out.append(_material(rng))
         elif r < 0.63: out.append("AttributeBegin"); depth += 1
         elif r < 0.70 and depth > 0: out.append("AttributeEnd"); depth -= 1
-        elif r < 0.75: out.append(f'AreaLightSource "diffuse" "rgb L" [{_vec(rng).replace("-", "")}]')
+        elif r < 0.73: out.append(f'AreaLightSource "diffuse" "rgb L" [{_vec(rng).replace("-", "")}]')
+        elif r < 0.75: out.append(f'AreaLightSource "diffuse" "blackbody L" [{rng.uniform(800, 15000):.2f} {rng.uniform(0.1, 50):.3f}]')
         elif r < 0.82 and not in_object:
             n = f"obj{len(names)}"; names.append(n); out.append(f'ObjectBegin "{n}"'); in_object = True; obj_depth = depth
         elif r < 0.88 and in_object and depth == obj_depth: out.append("ObjectEnd"); in_object = False

@@ -86,7 +86,6 @@ def test_errors_and_unsupported_constructs(tmp_path):
                                        "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
     assert rejected('WorldBegin\nShape "plymesh" "string filename" "quad.ply"\nWorldEnd\n')   # triangles only, as in the library
     assert rejected('WorldBegin\nShape "cylinder" "float radius" [1]\n' + tri + "WorldEnd\n")   # the reference crashes on it
-    assert rejected('WorldBegin\nAreaLightSource "diffuse" "blackbody L" [6500 1]\n' + tri + "WorldEnd\n")
     assert rejected('WorldBegin\nObjectBegin "a"\n' + tri + 'ObjectInstance "a"\nObjectEnd\nObjectInstance "a"\nWorldEnd\n')   # recursion
     assert rejected('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 7] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
     assert rejected('WorldBegin\nInclude "nosuchfile.pbrt"\n' + tri + "WorldEnd\n")
