@@ -103,6 +103,8 @@ GATHER_PEAK_RECORDS_PER_S = 2.19e11
 CONFIGS = {
     "c2": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[1]"),
+    "c2_fast": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
+                    served_from="lds/l1", what="BASELINE configs[1] through the opt-in fast tree (ptmi_config.fast_tree)"),
     "c3": dict(scene="cbox_quads.obj", width=1920, height=1080, spp=1024, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[2]"),
     "c5tile": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_phased",

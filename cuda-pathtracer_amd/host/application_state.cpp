@@ -449,6 +449,7 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     d.grid = (unsigned int*)upload(nullptr, (size_t)n * kGridSize * sizeof(unsigned int), "d_radiosity_grid_counts");
     d.rad_grid = (float4*)upload(nullptr, (size_t)n * kGridSize * sizeof(float4), "d_radiosity_grids");
     d.rays = (unsigned long long*)upload(nullptr, sizeof(unsigned long long), "d_radiosity_rays");
+    PTMI_HIP(hipMemset(d.rays, 0, sizeof(unsigned long long)));
 
     RadiosityParams prm;
     prm.num_iterations = num_iterations; prm.mc_samples = mc_samples; prm.use_monte_carlo = use_monte_carlo ? 1 : 0;

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
-for T in 0 256; do echo "== PTMI_SOLVER_TOP=$T"; PTMI_SOLVER_TOP=$T timeout -k 10 120 python tools/radiosity_probe.py 4; done
-echo "== no grid index (wrong results: upper bound of what the acos/atan2 per unblocked sample cost)"
-PTMI_SOLVER_TOP=0 PTMI_LIB=$PWD/ab_libs/libptmi_nogrid.so timeout -k 10 120 python tools/radiosity_probe.py 4
+for L in "" w7 w8; do
+  if [ -n "$L" ]; then export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so; fi
+  echo "== lib ${L:-shipped}"
+  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:80:0,1:3:1:9:0" 3 8,1
+done
