@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
-for L in "" w7 w8; do
-  if [ -n "$L" ]; then export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so; fi
-  echo "== lib ${L:-shipped}"
-  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:80:0,1:3:1:9:0" 3 8,1
+for L in park6 park7 park8; do
+  export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so
+  echo "== lib $L"
+  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:9:0" 3 8,1 | grep -v n_prims
 done
