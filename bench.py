@@ -274,6 +274,16 @@ def roofline_block(name, cfg, m, exact_workload):
                          "lds_served_node_visits": m["top_node_visit_share"],
                          "what": "node visits not served from the LDS top + primitive tests + material fetches per second vs tools/gather_rate.hip "
                                  "(profiles/r02_gather_rate.txt: uniform random 32-byte records of a 20 MB table; the walk's upper levels are hotter than that)"}
+    # `bound` keeps the contract's vocabulary ("hbm" | "mfma": divergent traversal has no MFMA form); what actually limits the
+    # workload, from the same counters: the VALU issue rate (sweep over an LDS-resident scene) or the latency of dependent
+    # record fetches (the large-scene walks: most wave cycles are spent waiting, neither HBM bandwidth nor issue slots run out)
+    if prof and out.get("valu"):
+        issue = out["valu"]["issue_frac_guide_2clk"]
+        wait = prof.get("wait_frac") or 0.0
+        out["limiter"] = ({"kind": "valu_issue", "frac": issue, "of": "one wave-instruction per 2 clocks per SIMD at 2.4 GHz (MI355X_MICROARCH.md)"}
+                          if issue >= wait else
+                          {"kind": "dependent_fetch_latency", "wait_frac": wait, "valu_issue_frac": issue,
+                           "of": "wave cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES); HBM-side bytes and issue slots are both far from their peaks"})
     out["note"] = ("achieved = HBM bytes per step / step time, frac <= 1 by construction; algorithmic_* follow SURVEY 8(d) and count "
                    "node/triangle/material reads, which are served from " + cfg["served_from"])
     return out

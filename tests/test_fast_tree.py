@@ -230,6 +230,15 @@ def test_fast_tree_config5_rows(R):
           f"LDS-served visits {st.top_node_visits / st.node_visits:.3f}")
     assert rmse < 1e-4
     assert st.node_visits / st.rays <= 30.0                      # node fetches per ray <= 30 (exact walk: 72.5)
+    # the same tile at BASELINE's FULL 2048 spp (1.07 G samples through the fast tree): one row against the oracle
+    R.set_config(spp=2048, collect_stats=False)
+    R.update_resolution(W, H, n_ranks=8, rank=3, row_block=8)
+    R.render_frame()
+    _, rad = R.read_image()
+    _, orad, _ = o.render(default_camera(), W, H, 2048, max_depth=depth, y0=y, y1=y + 1)
+    nd, rmse, mx = frame_diff(rad[100], orad[y])
+    print(f"config 5, row {y} at the full 2048 spp: {nd} of {W} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}")
+    assert rmse < 1e-4
     # whole frame at 16 spp: rows 1000..1003 against the oracle, tile union == unsharded frame
     R.set_config(spp=16, collect_stats=False)
     R.update_resolution(W, H); R.render_frame()

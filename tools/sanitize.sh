@@ -2,13 +2,13 @@
 # CPU-side sanitizer pass (GPU AddressSanitizer is not available on this pool): the oracle (gcc) and the product's host
 # code (hipcc, device instrumentation off) built with ASan + UBSan, then the CPU tests that exercise them - loader incl.
 # the 300-file differential fuzz, the PBRT parser incl. its 300-scene fuzz, BVH builder, camera, tiling, PNG writer,
-# solver/guided/view oracle tests.
+# solver/guided/view oracle tests, the fast tree's builder and host walk.
 set -e
 cd "$(dirname "$0")/.."
 OUT=${TMPDIR:-/tmp}/ptmi_sanitize; mkdir -p $OUT
 gcc -O1 -g -std=gnu11 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -march=x86-64-v2 -fsanitize=address,undefined -fno-omit-frame-pointer \
     -shared -o $OUT/libptmi_oracle_asan.so oracle/ptmi_oracle.c -lm
-for f in csrc/kernels.hip csrc/radiosity.hip csrc/dist.hip csrc/c_api.cpp host/application_state.cpp host/bvh.cpp host/file_manager.cpp host/pbrt_loader.cpp; do
+for f in csrc/kernels.hip csrc/radiosity.hip csrc/dist.hip csrc/c_api.cpp host/application_state.cpp host/bvh.cpp host/file_manager.cpp host/pbrt_loader.cpp host/wide_bvh.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -x hip -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
       -fno-slp-vectorize -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -c cuda-pathtracer_amd/$f -o $OUT/$(basename $f).o
 done
@@ -20,4 +20,4 @@ LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so
                    tests/test_guided_oracle.py tests/test_numerics_contract.py tests/test_host_logic.py -x -q -m "not gpu"
 echo "== product host code under clang ASan/UBSan"
 LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so) PTMI_LIB=$OUT/libptmi_asan.so \
-  python -m pytest tests/test_host_logic.py tests/test_pbrt_loader.py -x -q -m "not gpu"
+  python -m pytest tests/test_host_logic.py tests/test_pbrt_loader.py tests/test_fast_tree.py -x -q -m "not gpu"
