@@ -195,6 +195,33 @@ def test_fast_frames_of_small_scenes(R, name, sub, W, H, spp, depth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,frac", [(1, 0.5), (3, 0.3)])
+def test_guided_sampling_through_the_fast_tree(R, mode, frac):
+    """The grid / MIS branches read their PrecomputedCDF record through the hit's load-order index, which the fast walk takes
+    from its own per-triangle table: guided frames through the fast tree against the oracle (cbox subdivided, 128 triangles)."""
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path, 1, False)
+    o = OracleScene.load(path, 1, False)
+    rng = np.random.default_rng(40 + mode)
+    grids = (rng.random((o.n_prims, 256, 3)) ** 3).astype(F)
+    grids[rng.random(o.n_prims) < 0.2] = 0.0                     # some primitives without a grid: cosine fallback
+    R.set_radiosity_grids(grids); o.set_radiosity_grids(grids); o.set_mis_fraction(frac)
+    W, H, spp, depth = 64, 40, 6, 5
+    R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, sampling_mode=mode, mis_bsdf_fraction=frac, fast_tree=True)
+    try:
+        R.render_frame()
+        rgb, rad = R.read_image()
+        orgb, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, sampling_mode=mode)
+        nd, rmse, mx = frame_diff(rad, orad)
+        print(f"guided mode {mode} through the fast tree: {nd} pixels differ, RMSE {rmse:.3e}")
+        assert nd == 0 and (rgb == orgb).all()
+    finally:
+        R.set_config(sampling_mode=0, mis_bsdf_fraction=0.5, fast_tree=False)
+        R.set_radiosity_grids(None)
+
+
+@pytest.mark.gpu
 def test_fast_tree_on_a_quad_scene_keeps_the_exact_walk(R):
     path = os.path.join(SCENES, "cbox_quads.obj")
     R.load_scene(path); R.update_resolution(64, 64)
