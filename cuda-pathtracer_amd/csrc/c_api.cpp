@@ -271,7 +271,7 @@ int ptmi_run_radiosity_solver(ptmi_ctx* c, const ptmi_radiosity_params* p, ptmi_
         r.num_iterations = prm.num_iterations; r.mc_samples = prm.mc_samples; r.use_monte_carlo = prm.use_monte_carlo != 0;
         RadiosityStats st;
         r.runSolver(c->app.scene, c->app.render.d_jump, prm.enable_filtering != 0, prm.use_bilateral != 0,
-                    prm.filter_sigma_spatial, prm.filter_sigma_range, c->app.render.stream, &st);
+                    prm.filter_sigma_spatial, prm.filter_sigma_range, c->app.render.stream, &st, c->app.config.fast_tree);
         // the grids (Triangle/Quad::grid, ::radiosity_grid) stay on the device; the host copies the filter button and
         // "Use Raw CDFs" work from are fetched when one of them is pressed (sync_solver_grids)
         c->app.scene.h_count_grids.clear(); c->app.scene.h_radiosity_grids.clear();

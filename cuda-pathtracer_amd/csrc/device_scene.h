@@ -180,6 +180,7 @@ struct RadiosityBuffers {
     unsigned long long* rays = nullptr;   // shadow rays cast (1 counter)
     int n = 0;
     int bvh_depth = 0;                 // > 30: the visibility walk keeps the reference's explicit stack and drop rule
+    int fast_tree = 0;                 // 1: the visibility walk goes through DeviceScene's fast tree (opt-in, triangle scenes)
 };
 struct RadiosityParams {
     int num_iterations, mc_samples, use_monte_carlo, enable_filtering, use_bilateral;

@@ -162,6 +162,53 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
     }
 }
 
+// The same question through the opt-in fast tree (ptmi_config.fast_tree; csrc/wide_bvh.h): is any triangle other than the
+// pair's own two hit within max_dist.  Same triangles, same test arithmetic (anyhit_prim's triangle form on the tree's own
+// 36-byte records), conservative boxes: the answer is the reference's unless the reference's own slab test drops, by rounding,
+// the box of a triangle that the ray does hit.  Stack: one 8-byte entry per tree level, entry e of lane l at stack[e * kBlock].
+__device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float max_dist, int load_a, int load_b) {
+    const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
+    const uint32_t octinv = wide_octinv(inv);
+    int sp = 0;
+    uint32_t g_base = 0u, g_bits = (1u << 8) | (1u << octinv);
+    while (true) {
+        if ((g_bits & 0xffu) == 0u) {
+            if (sp == 0) return false;
+            sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y;
+        }
+        const int bit = 31 - __clz((int)(g_bits & 0xffu));
+        g_bits ^= 1u << bit;
+        const uint32_t child = (uint32_t)bit ^ octinv;
+        const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
+        if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
+        const uint4* q = sc.wnodes + 8 * (size_t)ni;
+        const WideStep st = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], o, inv, octinv, 1e-5f, max_dist);
+        uint32_t tris = st.tris;
+        while (tris) {
+            const int k = (int)st.tri_base + __ffs((int)tris) - 1;
+            tris &= tris - 1u;
+            const int li = sc.wload_index[k];
+            if (li == load_a || li == load_b) continue;
+            const float* r = sc.wprims + 9 * (size_t)k;
+            const f3 v0 = mk3(r[0], r[1], r[2]), edge1 = mk3(r[3], r[4], r[5]), edge2 = mk3(r[6], r[7], r[8]);
+            const f3 h = cross(d, edge2);                                  // anyhit_prim, triangle form
+            const float a = dot(edge1, h);
+            const float f = rcp_exact_normal(a);
+            const f3 s = o - v0;
+            const float u = f * dot(s, h);
+            const float m1 = min3_raw(fabsf(a) - 1e-8f, u, 1.0f - u);
+            if (!(m1 >= 0.0f)) continue;
+            const f3 qq = cross(s, edge1);
+            const float v = f * dot(d, qq);
+            const float t = f * dot(edge2, qq);
+            float m = min3_raw(m1, v, 1.0f - (u + v));
+            m = min_raw(m, t - 1e-5f);
+            if ((m >= 0.0f) & (t <= max_dist)) return true;
+        }
+        g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
+    }
+}
+
 // formfactor_rand_init (form_factors.h:85-89): curand_init(12345 + idx, idx, 0).  Block-synchronous: one 160x160 GF(2)
 // matrix T^(2^67 * 2^k) at a time is staged in LDS and applied by the threads whose idx has bit k set.
 __device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __restrict__ jump, bool have, unsigned int idx, Rng& out) {
@@ -199,8 +246,8 @@ __device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __res
 // the sample loop and F_ij of calculate_form_factors_mc_kernel (form_factors.h:259-365) for one surviving pair
 // The emitter's record is read again for every sample (it is L1-resident, and only the sample's first lines use it): its
 // 13 - 18 registers do not have to live through the visibility walk, where the kernel is short of them (7 waves per SIMD).
-template <bool HAS_QUADS, bool DEEP, bool RAD0>
-__device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, const float4* __restrict__ geo, int j, int slot_i, int slot_j,
+template <bool HAS_QUADS, bool DEEP, bool RAD0, bool WIDE>
+__device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, int i, const Geom& gi, const float4* __restrict__ geo, int j, int slot_i, int slot_j,
                                          int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays) {
     float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
     int valid_samples = 0;
@@ -221,7 +268,8 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, 
         const f3 ro = p_i + 1e-4f * gi.normal;
         const f3 rd = unit_vector(sample_dir);                                  // Ray's constructor normalises again (ray.h:9-12)
         rays++;
-        if (!visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) {
+        const bool blocked = WIDE ? visibility_blocked_wide(sc, wstack, ro, rd, r - 2e-4f, i, j) : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j);
+        if (!blocked) {
             visibility_sum += 1.0f; cos_i_sum += cos_theta_i; cos_j_sum += cos_theta_j; dist_sum += r;
             valid_samples++;
             const int grid_idx = direction_to_grid_index_local(sample_dir, gi.normal);
@@ -247,8 +295,8 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, const Geom& gi, 
 }
 
 // calculate_form_factors_kernel (form_factors.h:368-415) after its culling tests
-template <bool HAS_QUADS, bool DEEP>
-__device__ __forceinline__ float p2p_pair(const DeviceScene& sc, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays) {
+template <bool HAS_QUADS, bool DEEP, bool WIDE>
+__device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, int i, int j, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays) {
     const f3 vec_ij = gj.centroid - gi.centroid;
     const float r = length(vec_ij);
     const f3 dir_ij = div_scalar(vec_ij, r);
@@ -257,7 +305,7 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, const Geom& gi,
     const f3 ro = gi.centroid + 1e-4f * gi.normal;
     const f3 rd = unit_vector(dir_ij);
     rays++;
-    if (visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
+    if (WIDE ? visibility_blocked_wide(sc, wstack, ro, rd, r - 2e-4f, i, j) : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
     const float ff = (float)((double)(cos_theta_i * cos_theta_j * gj.area) / (PTMI_PI_D * (double)r * (double)r));
     return fmaxf(0.0f, ff);
 }
@@ -266,9 +314,17 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, const Geom& gi,
 // wait on L2, and more waves in flight are worth more than the spills cost - n = 8192: 4 / 5 / 6 / 7 / 8 waves 168.6 / 151.6 /
 // 139.0 / 134.8 / 133.5 ms, and 131.4 ms at 7 waves with the emitter's record re-read per sample (mc_pair); n = 2048: 7 waves
 // 14.5 ms, 8 waves 15.0 ms
-template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0>
-__global__ __launch_bounds__(kBlock, 7) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
+#ifndef PTMI_FF_WIDE_WAVES
+#define PTMI_FF_WIDE_WAVES 6
+#endif
+// WIDE: the visibility walk goes through the opt-in fast tree (visibility_blocked_wide); its node test wants ~80 registers, so
+// that build is bounded to 6 waves per SIMD (n = 8192: 4 / 5 / 6 waves 78.8 / 74.9 / 70.4 ms; the exact walk: 131.8) and keeps its
+// per-lane stack in dynamic LDS (depth x 2 KB per workgroup)
+template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
                                                             const uint32_t* __restrict__ jump) {
+    extern __shared__ uint2 ff_wstack[];
+    uint2* wstack = ff_wstack + threadIdx.x;
     __shared__ uint32_t M[160 * 5];
     __shared__ unsigned int counts[kGridSize];
     __shared__ float radg[RAD0 ? 3 * kGridSize : 1];
@@ -337,8 +393,8 @@ __global__ __launch_bounds__(kBlock, 7) void ptmi_form_factors(DeviceScene sc, R
             if (have) {
                 const int slot_j = rb.slot_of[e.x];
                 float F;
-                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0>(sc, gi, rb.geo, e.x, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
-                else F = p2p_pair<HAS_QUADS, DEEP>(sc, gi, load_geom(rb.geo, e.x), slot_i, slot_j, rays);
+                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0, WIDE>(sc, wstack, i, gi, rb.geo, e.x, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
+                else F = p2p_pair<HAS_QUADS, DEEP, WIDE>(sc, wstack, i, e.x, gi, load_geom(rb.geo, e.x), slot_i, slot_j, rays);
                 row[e.x] = F;
             }
             __syncthreads();
@@ -690,8 +746,16 @@ __global__ __launch_bounds__(kBlock) void ptmi_cdf_records(const void* __restric
 
 template <bool MC, bool Q_, bool D_>
 void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
-    if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
-    else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+    if constexpr (!Q_ && !D_) {
+        if (rb.fast_tree && sc.wnodes) {                   // the opt-in fast tree for the visibility walk
+            const size_t lds = (size_t)sc.w_depth * kBlock * sizeof(uint2);
+            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, true>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, true>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            return;
+        }
+    }
+    if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+    else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, false, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
 }
 template <bool MC>
 void launch_ff1(bool quads, bool deep, bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples,

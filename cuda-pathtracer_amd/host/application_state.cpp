@@ -405,7 +405,7 @@ void RadiosityState::cleanup() {
 }
 
 void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
-                               float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats) {
+                               float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats, bool fast_tree) {
     if (!scene.d_nodes) throw ArgError("runSolver: no scene loaded");
     const int n = (int)scene.h_primitives.size();
     if (n > 46340) throw ArgError("runSolver: more than 46340 primitives (the pair index i * n + j is an int in the reference too)");
@@ -439,6 +439,10 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         return p;
     };
     d.n = n; d.bvh_depth = scene.bvh_depth;
+    if (fast_tree && !scene.num_quads && scene.bvh_depth <= 30) {          // opt-in: built on first use, as for the render path
+        if (!scene.fastReady()) scene.buildFast();
+        d.fast_tree = 1;
+    }
     d.geo = (const float4*)upload(geo.data(), geo.size() * sizeof(float4), "d_radiosity_geo");
     d.slot_of = (const int*)upload(slot_of.data(), slot_of.size() * sizeof(int), "d_radiosity_slot_of");
     d.bsdf = (const float4*)upload(bsdf.data(), bsdf.size() * sizeof(float4), "d_radiosity_bsdf");

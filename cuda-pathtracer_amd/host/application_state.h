@@ -139,7 +139,8 @@ struct RadiosityState {
     bool host_grids_current = false;                               // h_radiosity_grid / h_grid are fetched on demand
     void fetchGrids();                                             // D2H of the two n*256 grids (33 + 8 MB at n = 8192)
     void runSolver(SceneState& scene, const uint32_t* d_jump, bool enable_filtering, bool use_bilateral,
-                   float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats);
+                   float filter_sigma_spatial, float filter_sigma_range, hipStream_t stream, RadiosityStats* stats,
+                   bool fast_tree = false /* AppConfig::fast_tree: the visibility walk through the opt-in 8-wide tree */);
     void readFormFactors(float* out) const;          // n*n floats, row = receiver
     void cleanup();                                  // application_state.h:779-787
     ~RadiosityState() { cleanup(); }

@@ -222,6 +222,29 @@ def test_guided_sampling_through_the_fast_tree(R, mode, frac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sub", [2, 3])
+def test_radiosity_solver_through_the_fast_tree(R, sub):
+    """ptmi_run_radiosity_solver with config.fast_tree: the visibility walk of the form-factor kernel (form_factors.h:143-208)
+    through the fast tree.  An any-hit answer can differ only for a shadow ray that grazes a box the reference's own slab test
+    drops by rounding (about one in 2e8 rays: 2 of 67 M form factors at 8192 primitives); on these scenes (512 and 2048
+    primitives, 2.6 M / 30.7 M shadow rays) the whole solution is required to be the oracle's, bit for bit, and is reported."""
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path, sub, False)
+    R.set_config(fast_tree=True)
+    try:
+        st = R.run_radiosity_solver()
+        got = R.radiosity_solution()
+        exp = OracleScene.load(path, sub, False).radiosity_solve(n_threads=min(os.cpu_count() or 8, 32))
+        nd = int((bits(got["form_factors"]) != bits(exp["form_factors"])).sum())
+        print(f"solver through the fast tree, {got['form_factors'].shape[0]} primitives, {st.rays} shadow rays: {nd} form factors differ; form factors {st.form_factor_ms:.2f} ms")
+        assert st.rays == exp["rays"] and nd == 0
+        for k in ("radiosity", "unshot", "grid", "radiosity_grid"):
+            assert (bits(got[k]) == bits(exp[k])).all(), k
+    finally:
+        R.set_config(fast_tree=False)
+
+
+@pytest.mark.gpu
 def test_fast_tree_on_a_quad_scene_keeps_the_exact_walk(R):
     path = os.path.join(SCENES, "cbox_quads.obj")
     R.load_scene(path); R.update_resolution(64, 64)

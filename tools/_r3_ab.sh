@@ -1,8 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
-for L in "" prio75 prio85; do
-  if [ -n "$L" ]; then export PTMI_LIB=$PWD/ab_libs/libptmi_$L.so; fi
-  echo "== lib ${L:-shipped}"
-  timeout -k 10 200 python tools/fast_probe.py 64 "1:3:1:80:0" 3 8,4 | grep -v n_prims
-done
+timeout -k 10 600 python -m pytest tests/test_fast_tree.py tests/test_radiosity_solver.py -m gpu -x -q -s --timeout=400 > gpurun_out/r3_tests_11.log 2>&1 || { tail -40 gpurun_out/r3_tests_11.log; exit 1; }
+grep -E "solver through|passed|failed" gpurun_out/r3_tests_11.log

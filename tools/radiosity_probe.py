@@ -20,8 +20,10 @@ want_oracle = "--oracle" in sys.argv
 kw = {}
 if "--p2p" in sys.argv: kw["use_monte_carlo"] = 0
 if "--samples" in sys.argv: kw["mc_samples"] = int(sys.argv[sys.argv.index("--samples") + 1])
+fast = "--fast" in sys.argv            # the visibility walk through the opt-in fast tree (ptmi_config.fast_tree)
 scene = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
 R = ptmi.Renderer(0)
+R.set_config(fast_tree=fast)
 for sub in subs:
     R.load_scene(scene, sub, False)
     n = R.scene_info()["n_prims"]
@@ -36,4 +38,6 @@ for sub in subs:
         t = time.time(); exp = o.radiosity_solve(**kw); dt = time.time() - t
         got = R.radiosity_solution()
         same = all((got[k].view(np.uint32) == exp[k].view(np.uint32)).all() for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"))
-        print(f"   oracle {dt:.2f} s on {os.cpu_count()} threads ({exp['rays'] / dt / 1e6:.1f} Mrays/s); bit-identical: {same}", flush=True)
+        ndiff = int((got["form_factors"].view(np.uint32) != exp["form_factors"].view(np.uint32)).sum())
+        print(f"   oracle {dt:.2f} s on {os.cpu_count()} threads ({exp['rays'] / dt / 1e6:.1f} Mrays/s); bit-identical: {same}; form factors that differ: {ndiff} of {n * n}, "
+              f"rays {st.rays} vs {exp['rays']}", flush=True)
