@@ -107,14 +107,19 @@ CONFIGS = {
                     served_from="lds/l1", what="BASELINE configs[1] through the opt-in fast tree (ptmi_config.fast_tree)"),
     "c3": dict(scene="cbox_quads.obj", width=1920, height=1080, spp=1024, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[2]"),
-    "c5tile": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_phased",
-                   served_from="l2/mall/hbm", what="BASELINE configs[4], one GPU's share (rank 3 of 8) at 64 of 2048 spp"),
-    "c5frame": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
-                    served_from="l2/mall/hbm", what="BASELINE configs[4], the WHOLE frame on one GPU at 64 of 2048 spp: the same kernel with a full GPU"),
+    "c5tile": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_wide",
+                   served_from="l2/mall/hbm", what="BASELINE configs[4], one GPU's share (rank 3 of 8) at 64 of 2048 spp; default walk of large triangle "
+                   "scenes: the certified walk - 8-wide tree + a per-ray proof that the reference's walk returns the same hit: bit-identical frames"),
+    "c5frame": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide",
+                    served_from="l2/mall/hbm", what="BASELINE configs[4], the WHOLE frame on one GPU at 64 of 2048 spp (default = certified walk)"),
+    "c5tile_packed": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_phased", traversal=4,
+                          served_from="l2/mall/hbm", what="c5tile through the reference's own tree (packed layout): rounds 1-2's walk, node for node the reference's"),
+    "c5frame_packed": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased", traversal=4,
+                           served_from="l2/mall/hbm", what="c5frame through the reference's own tree (packed layout)"),
     "c5tile_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_wide", fast=True,
-                        served_from="l2/mall/hbm", what="c5tile through the opt-in fast tree (ptmi_config.fast_tree: 8-wide SAH tree, same triangles and hit arithmetic)"),
+                        served_from="l2/mall/hbm", what="c5tile through the opt-in fast tree WITHOUT the certificate (ptmi_config.fast_tree: tolerance mode)"),
     "c5frame_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
-                         served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree"),
+                         served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree without the certificate"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
     "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
@@ -292,11 +297,21 @@ def roofline_block(name, cfg, m, exact_workload):
 def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pipelined=True):
     """counters frame (untimed, stats build) + warmup + `steps` timed frames of the loaded workload.
     run_steps(k, stats, pipelined) renders k steps (frames) and returns the list of their ptmi_stats."""
-    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False,
-                 fast_tree=bool(cfg.get("fast")))
+    # two counter frames where the timed walk is not the reference's own: (1) the reference's walk (forced: the packed layout) for
+    # SURVEY 8(d)'s algorithmic figure, which is defined on the reference's node visits and primitive tests; (2) the walk that is
+    # timed (certified / fast tree), for what it really fetches
+    fast = bool(cfg.get("fast"))
+    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False, fast_tree=False)
+    auto = r.set_traversal(-1)
+    own_walk = fast or (auto == r.CERTIFIED and not cfg.get("traversal"))
+    if auto == r.CERTIFIED:
+        r.set_traversal(r.PACKED)
     st_counts = r.render_frame()
-    quads = r.scene_info()["n_quads"] > 0
-    bytes_per_sample = algorithmic_bytes_per_sample(st_counts, quads)
+    r.set_traversal(cfg.get("traversal", -1))
+    st_walk = st_counts
+    if own_walk:
+        r.set_config(fast_tree=fast)
+        st_walk = r.render_frame()
     r.set_config(collect_stats=False)
     if warmup:
         run_steps(warmup, False, pipelined)
@@ -311,11 +326,15 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     return dict(elapsed=elapsed, steps=steps, kernel_ms=kernel_ms, launches=launches, visits=visits, frame_dev_s=frame_dev_s,
                 bytes_per_sample=bytes_per_sample, local_samples_per_step=float(n_local_px) * cfg["spp"],
                 streams=r.config.streams or (2 if n_local_px >= (1 << 18) else 1),
-                record_fetches_per_step=float(st_counts.node_visits - st_counts.top_node_visits + st_counts.prim_tests + st_counts.hits),
-                top_node_visit_share=round(st_counts.top_node_visits / max(st_counts.node_visits, 1), 4),
+                record_fetches_per_step=float(st_walk.node_visits - st_walk.top_node_visits + st_walk.prim_tests + st_walk.hits + (st_walk.hits if own_walk and not fast else 0)),
+                top_node_visit_share=round(st_walk.top_node_visits / max(st_walk.node_visits, 1), 4),
                 counters=dict(rays_per_sample=round(st_counts.rays / st_counts.samples, 3),
                               nodes_per_ray=round(st_counts.node_visits / st_counts.rays, 2),
-                              tests_per_ray=round(st_counts.prim_tests / st_counts.rays, 2)))
+                              tests_per_ray=round(st_counts.prim_tests / st_counts.rays, 2),
+                              **({"walk": "certified" if not fast else "fast tree (no certificate)",
+                                  "walk_nodes_per_ray": round(st_walk.node_visits / st_walk.rays, 2), "walk_tests_per_ray": round(st_walk.prim_tests / st_walk.rays, 2),
+                                  "cert_chain_per_hit": round(st_walk.cert_chain / max(st_walk.hits, 1), 6),
+                                  "cert_fallback_per_hit": round(st_walk.cert_fallback / max(st_walk.hits, 1), 8)} if own_walk else {})))
 
 
 def main():
@@ -445,6 +464,7 @@ def main():
     pipelined = args.pipeline
     if args.profile_pass:
         r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=args.segments, collect_stats=False, fast_tree=bool(cfg.get("fast")))
+        r.set_traversal(cfg.get("traversal", -1))
         run_steps(args.steps, False, pipelined)
         print(json.dumps({"profile_pass": name, "frames": args.steps, **ptmi_buildinfo.stamps()}), flush=True)
         r.close()
@@ -500,26 +520,30 @@ def main():
     if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
         extras = []
         loaded = None
-        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_fast", 6), ("c5frame", 2), ("c5frame_fast", 3)):
+        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_packed", 6), ("c5tile_fast", 6), ("c5frame", 3), ("c5frame_packed", 2), ("c5frame_fast", 3)):
             xcfg = dict(CONFIGS[xname])
             if xcfg["scene"] != loaded:                   # the four 1 M-triangle workloads share one load
                 load_scene(r, xcfg["scene"]); loaded = xcfg["scene"]
             allocate(xcfg)
             vs_exact = None
-            if xcfg.get("fast"):
-                # what the opt-in tree changes in the result, measured on this very workload: one frame through the exact walk and
-                # one through the fast tree from the same RNG state (update_resolution re-seeds), compared pixel by pixel
+            if xcfg.get("fast") or (xcfg["scene"] == "tess1m" and not xcfg.get("traversal")):
+                # what the other tree changes in the result, measured on this very workload: one frame through the reference's own tree
+                # (packed layout) and one through the timed walk (certified: must be 0 pixels; fast tree: reported) from the same
+                # RNG state (update_resolution re-seeds), compared pixel by pixel
                 frames = []
                 for fast in (False, True):
                     allocate(xcfg)
-                    r.set_config(spp=xcfg["spp"], max_depth=xcfg["max_depth"], segments_per_launch=0, collect_stats=False, fast_tree=fast)
+                    r.set_traversal(-1 if fast else r.PACKED)                     # against the reference's own tree, node for node
+                    r.set_config(spp=xcfg["spp"], max_depth=xcfg["max_depth"], segments_per_launch=0, collect_stats=False, fast_tree=fast and bool(xcfg.get("fast")))
                     r.render_frame(want_stats=False)
                     frames.append(r.read_image(rgb8=False)[1])
+                r.set_traversal(-1)
                 diff = frames[0].view(np.uint32) != frames[1].view(np.uint32)
                 vs_exact = {"pixels": int(frames[0].shape[0] * frames[0].shape[1]), "pixels_differ": int(diff.any(axis=-1).sum()),
                             "max_abs": float(np.abs(frames[0].astype(np.float64) - frames[1]).max()),
                             "rmse": float(np.sqrt(np.mean((frames[0].astype(np.float64) - frames[1]) ** 2))),
-                            "what": "float radiance of one frame of this workload, fast tree vs the reference's tree, same RNG state (bar: RMSE < 1e-4)"}
+                            "what": "float radiance of one frame of this workload, the timed walk vs the reference's own tree (packed layout), same RNG state "
+                                    "(certified walk: identical by construction; fast tree: bar RMSE < 1e-4)"}
                 allocate(xcfg)
             xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps
@@ -529,7 +553,7 @@ def main():
                            "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"],
                            "roofline": roofline_block(xname, xcfg, xm, True)})
             if vs_exact:
-                extras[-1]["fast_tree_vs_exact"] = vs_exact
+                extras[-1]["fast_tree_vs_exact" if xcfg.get("fast") else "certified_vs_reference_tree"] = vs_exact
         r.set_config(fast_tree=False)
         out["extra_configs"] = extras
 

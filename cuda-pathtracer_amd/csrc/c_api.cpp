@@ -422,6 +422,7 @@ int ptmi_render_frame(ptmi_ctx* c, ptmi_stats* stats) {
             stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
             stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
             stats->prim_tests = fs.prim_tests; stats->hits = fs.hits; stats->top_node_visits = fs.top_node_visits;
+            stats->cert_chain = fs.cert_chain; stats->cert_fallback = fs.cert_fallback;
         }
     });
 }
@@ -435,6 +436,7 @@ int ptmi_render_frames(ptmi_ctx* c, int n_frames, ptmi_stats* stats) {
             stats->seconds = fs.seconds; stats->bounce_kernel_ms = fs.bounce_kernel_ms; stats->bounce_launches = fs.bounce_launches; stats->path_visits = fs.path_visits;
             stats->samples = fs.samples; stats->rays = fs.rays; stats->node_visits = fs.node_visits;
             stats->prim_tests = fs.prim_tests; stats->hits = fs.hits; stats->top_node_visits = fs.top_node_visits;
+            stats->cert_chain = fs.cert_chain; stats->cert_fallback = fs.cert_fallback;
         }
     });
 }
@@ -561,10 +563,14 @@ int ptmi_debug_place_tiles(ptmi_ctx* c, int width, int height, int n_ranks, int 
 int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, int* out_mode) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");
-        need(force_mode >= -1 && force_mode <= 4, "force_mode must be -1..4");
+        need(force_mode >= -1 && (force_mode <= 4 || force_mode == TRAVERSAL_CERTIFIED), "force_mode must be -1..4 or 6");
         need(sweep_max_prims >= 0, "sweep_max_prims must be >= 0");
         SceneState& s = c->app.scene;
         s.force_traversal = force_mode; s.sweep_max_prims = sweep_max_prims;
+        if (force_mode == TRAVERSAL_CERTIFIED && s.d_nodes && !s.num_quads && !s.fastReady()) {
+            PTMI_HIP(hipSetDevice(c->app.device_id));
+            s.buildFast();
+        }
         s.chooseTraversal();
         if (out_mode) *out_mode = s.d_nodes ? s.d_scene.traversal : -1;
     });

@@ -68,6 +68,12 @@ struct DeviceScene {
     const float4* wmtab = nullptr;     // distinct (Kd, Ke) pairs, 2 float4 per row
     const int* wload_index = nullptr;  // fast order -> load-order primitive index
     const int* wref_slot = nullptr;    // fast order -> reference leaf-order slot (equal-t hits keep the smaller one, scene.h:89-90)
+    // TRAVERSAL_CERTIFIED: what the VERIFY phase and the fallback read (kernels.hip: bounce_wide_body, CERT)
+    const uint4* wanc = nullptr;       // per reference leaf: its ancestors' pre-order node indices (leaf included), 4 per chunk, 0xffffffff pads
+    const float4* wcert = nullptr;     // per fast-order triangle: (leaf box min, bits(first chunk << 5 | chunks of the leaf's list)) (leaf box max, 0)
+    float w_big = 0.0f;                // the scene's largest |coordinate|
+    const int* wfast_of_ref = nullptr; // reference leaf-order slot -> fast order
+    float w_guard = 0.0f;              // the boxes are padded for ray origins with |coordinate| <= w_guard; others take the reference's walk
 };
 // PACKED LAYOUT.  On the 1 M-triangle scene the phased walk is bound by the rate at which L2 misses are served (it runs at
 // the same speed with 2 and with 7 waves per SIMD, with and without half of its node reads moved to LDS): what counts is the
@@ -94,6 +100,8 @@ enum TraversalMode {
     TRAVERSAL_PACKED = 4,  // scenes too large for LDS: PHASED over the packed layout (sibling pairs, 36-byte triangles)
     TRAVERSAL_WIDE = 5,    // opt-in (ptmi_config.fast_tree): PHASED over the 8-wide SAH tree of csrc/wide_bvh.h; the one walk
                            // that does NOT visit the reference's nodes - same triangles, same hit arithmetic, other boxes
+    TRAVERSAL_CERTIFIED = 6,   // WIDE + a proof per ray that the reference's walk returns the same hit (slab tests of the hit
+                           // leaf's ancestors in the reference's tree, tie detection), else the reference's walk for that ray: exact
 };
 
 struct PathState {
@@ -124,7 +132,7 @@ struct FrameParams {
     int n_local = 0;
 };
 
-struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits, top_node_visits; };
+struct StatCounters { unsigned long long rays, node_visits, prim_tests, hits, top_node_visits, cert_chain, cert_fallback; };
 
 constexpr int kBlock = 256;
 constexpr int kXorwowJumpWords = 32 * 160 * 5;   // 32 matrices T^(2^67 * 2^k), 160 rows of 5 words

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_frame_begin(TileMap tm, PathState
     st.F[slot] = make_uint2(rng.v4, rng.d);
 }
 
-struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits, top_visits; };
+struct LaneCounters { unsigned int rays, node_visits, prim_tests, hits, top_visits, cert_chain, cert_fallback; };
 
 // Slab test of scene.h:66-81 against [t_min, closest_t]; returns false when the reference would `continue`.
 // `t0 > tmin_box ? t0 : tmin_box` is written fmaxf(t0, tmin_box): identical for every input because tmin_box /
@@ -608,13 +608,17 @@ __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, i
     }
     if (STATS) {
         unsigned long long r = cn.rays, nv = cn.node_visits, pt = cn.prim_tests, h = cn.hits, tv = cn.top_visits;
+        unsigned long long cc = cn.cert_chain, cf = cn.cert_fallback;
         for (int off = 32; off > 0; off >>= 1) {
             r += __shfl_down(r, off); nv += __shfl_down(nv, off); pt += __shfl_down(pt, off); h += __shfl_down(h, off); tv += __shfl_down(tv, off);
+            cc += __shfl_down(cc, off); cf += __shfl_down(cf, off);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&a.stats->rays, r); atomicAdd(&a.stats->node_visits, nv);
             atomicAdd(&a.stats->prim_tests, pt); atomicAdd(&a.stats->hits, h);
             if (tv) atomicAdd(&a.stats->top_node_visits, tv);
+            if (cc) atomicAdd(&a.stats->cert_chain, cc);
+            if (cf) atomicAdd(&a.stats->cert_fallback, cf);
         }
     }
 }
@@ -661,7 +665,7 @@ __device__ __forceinline__ void bounce_body(const BounceArgs& a) {
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
-    LaneCounters cn = {0, 0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
 
     for (int seg = 0; seg < a.segments; seg++) {
         if (!__any(alive)) break;
@@ -724,7 +728,7 @@ __device__ __forceinline__ void bounce_phased_body(const BounceArgs& a) {
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
-    LaneCounters cn = {0, 0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
 
     enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
     const int n_nodes = PACKED ? a.sc.n_pos : a.sc.n_nodes, prim_stride = a.sc.prim_stride;     // cursor >= n_nodes: walk finished
@@ -837,7 +841,19 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // Measured and dropped: a UNIFIED step (a lane's pending triangle and its next node fetched and tested in one step, two phases
 // to vote between): 92 registers, 5 waves per SIMD: 1 610 / 2 322 Msamples/s (an eighth / the whole 1 M-triangle frame) against
 // 1 719 / 2 405 for this form at 6 waves; bounded to 6 waves it spills inside the loop (867 / 1 100).
-template <bool STATS, bool GUIDED, bool BATCH>
+// CERT (TRAVERSAL_CERTIFIED): the same walk made EXACT.  The fast walk tests every triangle whose Moller-Trumbore test accepts
+// the ray up to the current closest_t (its boxes are conservative), with the reference's arithmetic; so its hit (t*, k*) is
+// the global minimum over all accepted triangles, and the reference's own walk (scene.h:50-110) returns exactly the same
+// hit if (1) it reaches k*'s leaf and (2) no second triangle is hit at exactly t*.  (1): the reference enters a node when
+// `!(min(t_exit, closest_t) < t_entry)` holds for it and all its ancestors, closest_t being whatever it is at that moment -
+// never below the final t*; the test is monotone in closest_t, so if every ancestor of k*'s leaf (leaf included) passes
+// with closest_t = t* it passes in the reference: a VERIFY phase evaluates exactly these ~20 slab tests (box_hit, the exact
+// walk's arithmetic) from a per-leaf list of ancestor node indices, four nodes per step, fetched in parallel - not a chain.
+// (2): every triangle hit at t* is tested by the fast walk too, so a tie shows as `t == closest_t` there.  A ray for which
+// (1) or (2) cannot be shown - a grazed box, a shared edge, an origin outside the range the boxes were padded for - is walked
+// again by the reference's own walk (intersect_lane) inside this kernel: about one ray in 10^9.  No hit at all needs no
+// check: the reference can only accept triangles the fast walk would have found.
+template <bool STATS, bool GUIDED, bool BATCH, bool CERT>
 __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -862,10 +878,12 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
-    LaneCounters cn = {0, 0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
 
-    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3 };
+    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3, PH_VERIFY = 4 };
     const float t_min = 1e-4f, t_lo = mt_t_lo(t_min);
+    bool need_exact = false;                  // CERT: this ray goes through the reference's own walk
+    uint32_t v_off = 0u; int v_left = 0;      // CERT: next 4-node chunk of the hit leaf's ancestor list, chunks left
     int phase = alive ? PH_NODE : PH_DONE;
     int segs_left = a.segments;
     int slot_hit = -1, sp = 0;
@@ -875,13 +893,75 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     uint32_t g_base = 0u, g_bits = (1u << 8) | (1u << octinv);      // the root: slot 0 of a virtual parent
     uint32_t t_base = 0u, t_mask = 0u;
     if (STATS && alive) cn.rays++;
+    // where the walk goes when it has run out of nodes and triangles
+    auto after_walk = [&]() -> int {
+        if (!CERT) return PH_SHADE;
+        if (!need_exact && slot_hit < 0) return PH_SHADE;
+        v_left = -1;                                                   // first the one-fetch certificate, then (rarely) the chain
+        return PH_VERIFY;
+    };
+    auto origin_in_range = [&]() { return fmaxf(fabsf(p.o.x), fmaxf(fabsf(p.o.y), fabsf(p.o.z))) <= a.sc.w_guard; };
+    if (CERT && alive && !origin_in_range()) { need_exact = true; g_bits = 1u << 8; phase = after_walk(); }
 
     while (true) {
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_prim = __popcll(__ballot(phase == PH_PRIM));
         const int c_shade = __popcll(__ballot(phase == PH_SHADE));
-        if (c_node + c_prim + c_shade == 0) break;
-        if (c_node >= c_prim && c_node >= c_shade) {
+        const int c_verify = CERT ? __popcll(__ballot(phase == PH_VERIFY)) : 0;
+        if (c_node + c_prim + c_shade + c_verify == 0) break;
+        if (CERT && c_verify > 0 && c_verify >= c_node && c_verify >= c_prim && c_verify >= c_shade) {
+            if (phase == PH_VERIFY) {
+                if (!need_exact && v_left < 0) {
+                    // ONE fetch: the box of the hit triangle's leaf in the reference's tree.  Boxes are nested, so if the hit point
+                    // Q = o + t* d lies inside the LEAF's box by eps on every face, it lies inside every ancestor's by at least
+                    // as much - and eps = 2^-20 (|o_a| + big) is more than the reference's slab arithmetic can be off by on any box
+                    // of the scene: t0' = fl(fl(lo - o) fl(1 / d)) is within 3 * 2^-24 |lo - o| / |d| of the true plane distance,
+                    // Q_a' = fl(o_a + fl(t* d_a)) within 2 * 2^-24 (|o_a| + |t* d_a|) of Q_a, |lo_a - o_a| and |t* d_a| <= |o_a| + big.
+                    // Then every entry distance comes out <= t*, every exit distance >= t*, and `!(min(exit, closest_t) < entry)`
+                    // holds whatever closest_t >= t* the reference carries there.  A direction component below 2^-60 (1 / d near
+                    // overflow) or a point within eps of a face goes to the chain of exact slab tests instead.
+                    const float4 lo = a.sc.wcert[2 * (size_t)slot_hit], hi = a.sc.wcert[2 * (size_t)slot_hit + 1];
+                    const f3 q = p.o + closest_t * p.d;
+                    const float big = a.sc.w_big;
+                    const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + big), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + big),
+                                ez = 9.5367431640625e-7f * (fabsf(p.o.z) + big);
+                    const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
+                    const bool finite_slopes = fabsf(p.d.x) >= 8.673617379884035e-19f && fabsf(p.d.y) >= 8.673617379884035e-19f && fabsf(p.d.z) >= 8.673617379884035e-19f;
+                    if (inside && finite_slopes) phase = PH_SHADE;
+                    else {
+                        const uint32_t ref = __float_as_uint(lo.w);
+                        v_off = ref >> 5; v_left = (int)(ref & 31u);
+                        inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));       // the reference's 1 / d for its slab tests
+                        if (STATS) cn.cert_chain++;
+                    }
+                } else if (!need_exact) {
+                    const uint4 idx = a.sc.wanc[v_off];
+                    v_off++; v_left--;
+                    const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
+                    float4 n0[4], n1[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];      // padding repeats the root
+                        n0[c] = a.sc.nodes[2 * (size_t)j]; n1[c] = a.sc.nodes[2 * (size_t)j + 1];
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) ok = ok && box_hit(n0[c], n1[c], p.o, inv, t_min, closest_t);
+                    if (STATS) cn.node_visits += 4;
+                    if (!ok) need_exact = true;
+                    else if (v_left == 0) phase = PH_SHADE;
+                }
+                if (need_exact) {                                      // the reference's walk itself, for this ray only
+                    float t_ref = 0.0f; int slot_ref = -1;
+                    const bool h = intersect_lane<false, STATS>(a.sc.nodes, a.sc.prims, a.sc.prim_stride, a.sc.n_nodes, true, p.o, p.d, t_min, FLT_MAX,
+                                                                t_ref, slot_ref, cn);
+                    closest_t = h ? t_ref : FLT_MAX;
+                    slot_hit = h ? a.sc.wfast_of_ref[slot_ref] : -1;
+                    need_exact = false; phase = PH_SHADE;
+                    if (STATS) cn.cert_fallback++;
+                }
+            }
+        } else if (c_node >= c_prim && c_node >= c_shade) {
             if (phase == PH_NODE) {
                 if ((g_bits & 0xffu) == 0u) { sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y; }
                 const int bit = 31 - __clz((int)(g_bits & 0xffu));
@@ -904,7 +984,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
                 t_base = st.tri_base; t_mask = st.tris;
                 if (t_mask) phase = PH_PRIM;
-                else if ((g_bits & 0xffu) == 0u && sp == 0) phase = PH_SHADE;
+                else if ((g_bits & 0xffu) == 0u && sp == 0) phase = after_walk();
             }
         } else if (c_prim >= c_shade) {
             if (phase == PH_PRIM) {
@@ -918,10 +998,11 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 if (ok) {
                     if (tt < closest_t) { closest_t = tt; slot_hit = k; }
                     else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
-                        if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
+                        if (CERT) need_exact = true;                       // a tie: let the reference's walk decide
+                        else if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
                     }
                 }
-                if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : PH_SHADE;
+                if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : after_walk();
             }
         } else {
             if (phase == PH_SHADE) {
@@ -936,6 +1017,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     g_base = 0u; g_bits = (1u << 8) | (1u << octinv);
                     phase = PH_NODE;
                     if (STATS) cn.rays++;
+                    if (CERT && !origin_in_range()) { need_exact = true; g_bits = 1u << 8; phase = after_walk(); }
                 }
             }
         }
@@ -947,9 +1029,9 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
 #ifndef PTMI_WIDE_WAVES
 #define PTMI_WIDE_WAVES 6
 #endif
-template <bool STATS, bool GUIDED, bool BATCH>
+template <bool STATS, bool GUIDED, bool BATCH, bool CERT>
 __global__ __launch_bounds__(kBlock, PTMI_WIDE_WAVES) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
-    bounce_wide_body<STATS, GUIDED, BATCH>(a);
+    bounce_wide_body<STATS, GUIDED, BATCH, CERT>(a);
     publish_count(a);
 }
 
@@ -962,7 +1044,7 @@ extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and cle
 #endif
 
 size_t bounce_lds_bytes(const DeviceScene& sc) {
-    if (sc.traversal == TRAVERSAL_WIDE) return (size_t)sc.w_top * kWideNodeDwords * 4 + (size_t)sc.w_depth * kBlock * sizeof(uint2);
+    if (sc.traversal == TRAVERSAL_WIDE || sc.traversal == TRAVERSAL_CERTIFIED) return (size_t)sc.w_top * kWideNodeDwords * 4 + (size_t)sc.w_depth * kBlock * sizeof(uint2);
     size_t b = 0;
     const bool geom = sc.lds_resident || sc.traversal == TRAVERSAL_SWEEP;
     if (geom) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);
@@ -1029,17 +1111,22 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
             break;
         case TRAVERSAL_PACKED: with_bounce_qs<4, false>(a, (size_t)sc.n_top * 2 * sizeof(float4), f); break;
         case TRAVERSAL_WIDE:
+        case TRAVERSAL_CERTIFIED: {
+            const bool cert = sc.traversal == TRAVERSAL_CERTIFIED;
+#define PTMI_WIDE(S_, G_, B_) do { if (cert) f(ptmi_bounce_wide<S_, G_, B_, true>, lds); else f(ptmi_bounce_wide<S_, G_, B_, false>, lds); } while (0)
             switch ((a.stats ? 4 : 0) | (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
-                case 0: f(ptmi_bounce_wide<false, false, false>, lds); break;
-                case 1: f(ptmi_bounce_wide<false, false, true>, lds); break;
-                case 2: f(ptmi_bounce_wide<false, true, false>, lds); break;
-                case 3: f(ptmi_bounce_wide<false, true, true>, lds); break;
-                case 4: f(ptmi_bounce_wide<true, false, false>, lds); break;
-                case 5: f(ptmi_bounce_wide<true, false, true>, lds); break;
-                case 6: f(ptmi_bounce_wide<true, true, false>, lds); break;
-                default: f(ptmi_bounce_wide<true, true, true>, lds); break;
+                case 0: PTMI_WIDE(false, false, false); break;
+                case 1: PTMI_WIDE(false, false, true); break;
+                case 2: PTMI_WIDE(false, true, false); break;
+                case 3: PTMI_WIDE(false, true, true); break;
+                case 4: PTMI_WIDE(true, false, false); break;
+                case 5: PTMI_WIDE(true, false, true); break;
+                case 6: PTMI_WIDE(true, true, false); break;
+                default: PTMI_WIDE(true, true, true); break;
             }
+#undef PTMI_WIDE
             break;
+        }
         default:
             if (sc.lds_resident) with_bounce_qs<TRAVERSAL_STACK, true>(a, lds, f); else with_bounce_qs<TRAVERSAL_STACK, false>(a, lds, f);
             break;
@@ -1132,7 +1219,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_render_radiosity(DeviceScene sc, 
         rng = Rng{e.x, e.y, e.z, e.w, f.x, f.y};                                      // curandState local_rng = rand_state[pixel_index]
     }
     f3 color = mk3(0.0f, 0.0f, 0.0f);
-    LaneCounters cn = {0, 0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < fp.spp; s++) {
         f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         if (live) camera_ray(fp, tm, x, y, rng, o, d);
@@ -1183,7 +1270,7 @@ __global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_k(DeviceScene sc,
     const bool live = i < n;
     const int j = live ? i : 0;
     const f3 ro = mk3(o[3 * j], o[3 * j + 1], o[3 * j + 2]), rd = mk3(d[3 * j], d[3 * j + 1], d[3 * j + 2]);
-    LaneCounters cn = {0, 0, 0, 0, 0};
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
     float t = 0.0f; int k = -1;
     const bool h = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, ro, rd, t_min, t_max, t, k, cn);
     if (!live) return;
@@ -1202,7 +1289,7 @@ void launch_debug_intersect(const DeviceScene& sc, int n, const float* o, const 
     const size_t lds = (size_t)sc.stack_entries * kBlock * sizeof(int);
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
 #define PTMI_DBG(M_, Q_) hipLaunchKernelGGL((ptmi_debug_intersect_k<M_, Q_>), grid, block, lds, s, sc, n, o, d, t_min, t_max, hit, prim, t, p, nrm)
-    const int walk = sc.traversal == TRAVERSAL_PHASED || sc.traversal == TRAVERSAL_PACKED ? TRAVERSAL_LANE : sc.traversal;   // the phased kernels walk like LANE
+    const int walk = sc.traversal == TRAVERSAL_PHASED || sc.traversal == TRAVERSAL_PACKED || sc.traversal == TRAVERSAL_CERTIFIED ? TRAVERSAL_LANE : sc.traversal;   // the phased kernels walk like LANE
     switch (walk * 2 + (sc.has_quads ? 1 : 0)) {
         case 0: PTMI_DBG(TRAVERSAL_SWEEP, false); break;
         case 1: PTMI_DBG(TRAVERSAL_SWEEP, true); break;

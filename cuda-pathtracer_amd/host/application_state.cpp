@@ -200,6 +200,10 @@ void SceneState::upload() {
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
     buildPacked();
+    // Large triangle scenes (the ones the packed layout is built for): the 8-wide tree + the certificate data of
+    // TRAVERSAL_CERTIFIED - the default walk there: the reference's hit for every ray, by proof or by its own walk, at about
+    // twice the exact walk's rate (1 M triangles: +1.3 s of loading, +145 MB)
+    if (d_gnodes && !num_quads && bvh_depth <= 62 && certified_default) buildFast();
     chooseTraversal();
 }
 
@@ -313,12 +317,14 @@ void SceneState::buildPacked() {
 }
 
 void SceneState::freeFast() {
-    void* ptrs[] = {d_wnodes, d_wprims, d_wmats, d_wmtab, d_wload_index, d_wref_slot};
+    void* ptrs[] = {d_wnodes, d_wprims, d_wmats, d_wmtab, d_wload_index, d_wref_slot, d_wanc, d_wcert, d_wfast_of_ref};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d_wnodes = nullptr; d_wprims = nullptr; d_wmats = d_wmtab = nullptr; d_wload_index = d_wref_slot = nullptr;
+    d_wanc = nullptr; d_wcert = nullptr; d_wfast_of_ref = nullptr;
     h_wide.clear();
     d_scene.wnodes = nullptr; d_scene.w_nodes = d_scene.w_top = d_scene.w_depth = 0; d_scene.wprims = nullptr; d_scene.wmats = nullptr;
     d_scene.wmtab = nullptr; d_scene.wload_index = nullptr; d_scene.wref_slot = nullptr;
+    d_scene.wanc = nullptr; d_scene.wcert = nullptr; d_scene.wfast_of_ref = nullptr; d_scene.w_guard = 0.0f; d_scene.w_big = 0.0f;
 }
 
 // The opt-in fast tree (csrc/wide_bvh.h): same triangles, same hit arithmetic, own boxes.  Per-triangle arrays are re-ordered
@@ -365,6 +371,44 @@ void SceneState::buildFast() {
     d_wmtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_wmtab");
     d_wload_index = (int*)upload_vec(h_wide.tri_load_index.data(), (size_t)n * sizeof(int), "d_wload_index");
     d_wref_slot = (int*)upload_vec(ref_slot.data(), (size_t)n * sizeof(int), "d_wref_slot");
+    // TRAVERSAL_CERTIFIED: per reference leaf the pre-order indices of its ancestors (root first, the leaf itself last) in chunks
+    // of four, padded with 0xffffffff; per fast-order triangle where its leaf's list starts and how many chunks it has; and the
+    // way back from a reference leaf-order slot to the fast order (for the rays that take the reference's walk)
+    {
+        const int nn = (int)bvh_nodes.size();
+        std::vector<int> parent((size_t)nn, -1);
+        for (int i = 0; i < nn; i++) if (!bvh_nodes[i].isLeaf()) { parent[bvh_nodes[i].left_child] = i; parent[bvh_nodes[i].right_child] = i; }
+        std::vector<uint32_t> anc;                       // 4 per chunk
+        std::vector<uint32_t> leaf_ref((size_t)nn, 0u);  // leaf node -> first chunk << 5 | chunks
+        std::vector<int> path;
+        bool fits = true;
+        for (int i = 0; i < nn; i++) {
+            if (!bvh_nodes[i].isLeaf()) continue;
+            path.clear();
+            for (int x = i; x >= 0; x = parent[x]) path.push_back(x);
+            const size_t first_chunk = anc.size() / 4, chunks = (path.size() + 3) / 4;
+            if (chunks > 31 || first_chunk >= (1u << 27)) { fits = false; break; }
+            for (size_t k = path.size(); k-- > 0;) anc.push_back((uint32_t)path[k]);
+            while (anc.size() % 4) anc.push_back(0xffffffffu);
+            leaf_ref[i] = (uint32_t)(first_chunk << 5) | (uint32_t)chunks;
+        }
+        if (fits && bvh_depth <= 62) {
+            std::vector<int> leaf_of_slot((size_t)n, 0), fast_of_ref((size_t)n, 0);
+            for (int i = 0; i < nn; i++) if (bvh_nodes[i].isLeaf()) for (int k = 0; k < bvh_nodes[i].prim_count; k++) leaf_of_slot[bvh_nodes[i].left_child + k] = i;
+            std::vector<float4> cert((size_t)2 * n);           // the leaf's box as the reference built it + where its ancestor list is
+            for (int k = 0; k < n; k++) {
+                const int leaf = leaf_of_slot[ref_slot[k]];
+                const AABB& bx = bvh_nodes[leaf].bbox;
+                float ref_bits; std::memcpy(&ref_bits, &leaf_ref[leaf], 4);
+                cert[(size_t)2 * k] = make_float4(bx.min.x, bx.min.y, bx.min.z, ref_bits);
+                cert[(size_t)2 * k + 1] = make_float4(bx.max.x, bx.max.y, bx.max.z, 0.0f);
+                fast_of_ref[ref_slot[k]] = k;
+            }
+            d_wanc = (uint4*)upload_vec(anc.data(), anc.size() * sizeof(uint32_t), "d_wanc");
+            d_wcert = (float4*)upload_vec(cert.data(), cert.size() * sizeof(float4), "d_wcert");
+            d_wfast_of_ref = (int*)upload_vec(fast_of_ref.data(), fast_of_ref.size() * sizeof(int), "d_wfast_of_ref");
+        }
+    }
     // LDS of a workgroup: the walk's stack (one 8-byte entry per lane and tree level below the root: a group is pushed only
     // while a deeper one is entered) + the top of the tree, whole levels while they fit wide_top_nodes AND six workgroups
     // still share a CU's 160 KB (6 waves per SIMD, what the kernel's 80 registers allow; a 9-level tree with the 8-level
@@ -376,6 +420,7 @@ void SceneState::buildFast() {
         if (h_wide.level_start[l] <= wide_top_nodes && (long long)h_wide.level_start[l] * kWideNodeDwords * 4 <= lds_budget) top = h_wide.level_start[l];
     d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = stack_entries;
     d_scene.wprims = d_wprims; d_scene.wmats = d_wmats; d_scene.wmtab = d_wmtab; d_scene.wload_index = d_wload_index; d_scene.wref_slot = d_wref_slot;
+    d_scene.wanc = d_wanc; d_scene.wcert = d_wcert; d_scene.wfast_of_ref = d_wfast_of_ref; d_scene.w_guard = h_wide.origin_guard; d_scene.w_big = 0.25f * h_wide.origin_guard;
 }
 
 void SceneState::setRadiosity(const float* rgb) {
@@ -592,12 +637,15 @@ void SceneState::chooseTraversal() {
     if (!d_nodes) return;
     if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
-    else d_scene.traversal = d_scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED;
+    else d_scene.traversal = d_scene.gnodes ? (certified_default && d_scene.wnodes && d_scene.wcert ? TRAVERSAL_CERTIFIED : TRAVERSAL_PACKED) : TRAVERSAL_PHASED;
     // PHASED: measured faster than the segment-synchronous LANE walk from 128 primitives up (LDS-resident or not); PACKED: the
     // phased walk over the packed layout of scenes too large for LDS; LANE stays available through the override
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;
     if (d_scene.traversal == TRAVERSAL_SWEEP && !d_scene.lds_resident) d_scene.traversal = TRAVERSAL_LANE;   // the sweep reads through LDS
     if (d_scene.traversal == TRAVERSAL_PACKED && !d_scene.gnodes) d_scene.traversal = TRAVERSAL_PHASED;
+    // CERTIFIED needs the fast tree and the ancestor lists (triangle scenes of depth <= 62); otherwise the exact walk it stands for
+    if (d_scene.traversal == TRAVERSAL_CERTIFIED && !(d_scene.wnodes && d_scene.wanc))
+        d_scene.traversal = (int)h_primitives.size() <= sweep_max_prims && d_scene.lds_resident ? TRAVERSAL_SWEEP : (d_scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,8 +833,9 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         g.scene.buildFast();
     DeviceScene scene = g.scene.d_scene;
     if (g.config.fast_tree && g.scene.fastReady()) scene.traversal = TRAVERSAL_WIDE;
+    if (scene.traversal == TRAVERSAL_CERTIFIED && !(g.scene.fastReady() && scene.wanc)) scene.traversal = scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED;
     const int trav = scene.traversal;
-    const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED || trav == TRAVERSAL_WIDE;
+    const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED || trav == TRAVERSAL_WIDE || trav == TRAVERSAL_CERTIFIED;
     const long long fit_pct = phased ? 120 : 30;
     const long long wave_slots = g.config.segments_per_launch > 0 || !(phased || trav == TRAVERSAL_SWEEP)
                                      ? 0 : bounce_resident_waves(scene, fp, g.config.collect_stats, g.n_cus);
@@ -953,7 +1002,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
             StatCounters c;
             PTMI_HIP(hipMemcpy(&c, r.d_stats, sizeof c, hipMemcpyDeviceToHost));
             stats->rays = c.rays; stats->node_visits = c.node_visits; stats->prim_tests = c.prim_tests; stats->hits = c.hits;
-            stats->top_node_visits = c.top_node_visits;
+            stats->top_node_visits = c.top_node_visits; stats->cert_chain = c.cert_chain; stats->cert_fallback = c.cert_fallback;
         }
     }
 }

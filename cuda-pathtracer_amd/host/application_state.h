@@ -72,11 +72,15 @@ struct SceneState {
     // opt-in fast tree for TRAVERSAL_WIDE (csrc/wide_bvh.h), built at the first frame that asks for it (AppConfig::fast_tree)
     WideBVH h_wide;
     WideBVHParams wide_params;
+    bool certified_default = true;                   // scenes that get the packed layout and have no quads walk CERTIFIED by default
     int wide_top_nodes = 80;                         // whole levels of the fast tree kept in LDS while they fit this many nodes (128 B each)
     uint4* d_wnodes = nullptr;
     float* d_wprims = nullptr;
     float4 *d_wmats = nullptr, *d_wmtab = nullptr;
     int *d_wload_index = nullptr, *d_wref_slot = nullptr;
+    uint4* d_wanc = nullptr;                         // TRAVERSAL_CERTIFIED: ancestor lists of the reference's leaves, see buildFast
+    float4* d_wcert = nullptr;
+    int* d_wfast_of_ref = nullptr;
     void buildFast();                                // host build + upload; throws ArgError for scenes with quads
     void freeFast();
     bool fastReady() const { return d_wnodes != nullptr; }
@@ -225,7 +229,8 @@ void debugPlaceTiles(int width, int height, int n_ranks, int row_block, const un
 
 struct FrameStats {
     double seconds = 0, bounce_kernel_ms = 0;
-    uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0, top_node_visits = 0;
+    uint64_t bounce_launches = 0, path_visits = 0, samples = 0, rays = 0, node_visits = 0, prim_tests = 0, hits = 0, top_node_visits = 0,
+             cert_chain = 0, cert_fallback = 0;
 };
 
 struct ApplicationState {

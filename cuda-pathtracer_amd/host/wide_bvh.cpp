@@ -124,14 +124,18 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
     if (n == 0) throw std::invalid_argument("fast tree: scene has no primitives");
     for (const Primitive& p : prims) if (p.type != PRIM_TRIANGLE) throw std::invalid_argument("fast tree: triangle scenes only");
 
-    // triangle boxes, padded: the kernel's plane distances carry a few ulp of |p - o| + extent, so every box is widened by
-    // 2^-18 of the scene's largest coordinate (cbox: 4e-5) plus the reference's own 1e-6 (bvh.h:108-114) before anything else
+    // triangle boxes, padded.  The node test computes a plane distance as fma(q, 2^e / d, (p - o) / d): its error is a few
+    // 2^-24 of |p - o| + the node's extent, i.e. of |o| + the scene's largest coordinate `big`.  For origins with |coordinate|
+    // <= 4 big (the certified walk sends any other ray through the reference's walk) that is below 5 big * 4 * 2^-24 =
+    // 2^-19.7 big; every box is widened by 2^-16 big (cbox: 9e-5, a two-hundredth of the 1 M-triangle scene's cell) plus the
+    // reference's own 1e-6 (bvh.h:108-114): an order of magnitude of slack, so that no triangle the ray hits is ever culled
     std::vector<Box> pbox((size_t)n);
     std::vector<std::array<float, 3>> pcen((size_t)n);
     float big = 0.0f;
     for (const Primitive& p : prims) for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
     if (!(big < 1.0e9f)) throw std::invalid_argument("fast tree: coordinates must stay below 1e9");
-    const float pad = big * (1.0f / 262144.0f) + 1e-6f;
+    const float pad = big * (1.0f / 65536.0f) + 1e-6f;
+    out.origin_guard = 4.0f * big;
     for (int i = 0; i < n; i++) {
         const Primitive& p = prims[i];
         Box b;

@@ -21,6 +21,7 @@ struct WideBVH {
     std::vector<int> tri_load_index;    // fast order -> load-order primitive index
     std::vector<int> level_start;       // first node index of every level (+ a final entry = n_nodes)
     int n_nodes = 0, depth = 0;         // depth: levels of wide nodes (root = 1) = most entries the walk's stack ever holds + 1
+    float origin_guard = 0.0f;          // the triangle boxes are padded for ray origins with |coordinate| <= this (4 x the scene's largest)
     double sah = 0.0;                   // for inspection: sum of (child area / root area) over all children of all nodes
     int binary_nodes = 0, binary_leaves = 0;
     int fill_hist[9] = {}, leaf_hist[4] = {};   // nodes by number of children; leaf children by number of triangles

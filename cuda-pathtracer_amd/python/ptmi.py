@@ -61,7 +61,8 @@ class RadiosityStats(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("path_visits", C.c_uint64),
                 ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("top_node_visits", C.c_uint64)]
+                ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("top_node_visits", C.c_uint64),
+                ("cert_chain", C.c_uint64), ("cert_fallback", C.c_uint64)]
 
 
 class PtmiError(RuntimeError):
@@ -503,7 +504,7 @@ class Renderer:
         return out_rgb, out_rad
 
     # --- test hooks ---
-    SWEEP, LANE, STACK, PHASED, PACKED = 0, 1, 2, 3, 4
+    SWEEP, LANE, STACK, PHASED, PACKED, WIDE, CERTIFIED = 0, 1, 2, 3, 4, 5, 6
 
     def set_traversal(self, force_mode=-1, sweep_max_prims=64):
         """Returns the traversal mode in effect for the loaded scene (-1 if none)."""

@@ -118,6 +118,9 @@ typedef struct {
     uint64_t samples;          /* local pixels * spp */
     uint64_t rays, node_visits, prim_tests, hits;   /* only with collect_stats */
     uint64_t top_node_visits;  /* of node_visits, those served from the LDS-staged top of the packed layout (large scenes; else 0) */
+    uint64_t cert_chain;       /* certified walk (traversal 6), with collect_stats: hits whose one-fetch certificate did not apply and
+                                * whose leaf's ancestors were slab-tested one by one */
+    uint64_t cert_fallback;    /* ... and rays that were walked again by the reference's own walk (ties, grazed boxes, far origins) */
 } ptmi_stats;
 
 /* RadiosityState + the filter switches of AppConfig (application_state.h:207-209, 290-291), defaults in comments */
@@ -311,6 +314,8 @@ int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int ro
 /* Overrides how ptmi_bounce walks the BVH (results are identical in every mode): force_mode -1 = automatic,
  * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases,
  * 4 = 3 over the packed layout (sibling-pair node order, 36-byte triangles; only where that layout was built, else 3);
+ * 6 = certified: the 8-wide tree of ptmi_config.fast_tree + a per-ray proof that the reference's walk returns the same hit,
+ *     else the reference's walk for that ray (triangle scenes; results identical, the node / test counters are its own);
  * sweep_max_prims = largest scene (primitives)
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */

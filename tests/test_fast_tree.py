@@ -244,6 +244,84 @@ def test_radiosity_solver_through_the_fast_tree(R, sub):
         R.set_config(fast_tree=False)
 
 
+def render_vs_oracle(R, o, W, H, spp, depth, cam=None):
+    R.update_resolution(W, H)
+    R.set_config(spp=spp, max_depth=depth, collect_stats=True, segments_per_launch=0)
+    st = R.render_frame()
+    rgb, rad = R.read_image()
+    orgb, orad, ost = o.render(cam if cam is not None else default_camera(), W, H, spp, max_depth=depth)
+    nd, rmse, mx = frame_diff(rad, orad)
+    return st, ost, nd, (rgb == orgb).all()
+
+
+@pytest.mark.gpu
+def test_certified_walk_is_exact_and_the_default_of_large_triangle_scenes(R):
+    """TRAVERSAL_CERTIFIED (kernels.hip: bounce_wide_body, CERT): the fast tree's hit + a proof per ray that the reference's walk
+    returns the same one, else the reference's walk for that ray.  65 536 triangles (more than the 8 192 nodes from which the
+    packed layout is built): the automatic choice must be the certified walk and the frame the oracle's, bit for bit; the share
+    of hits that needed the ancestor chain and of rays that were walked again is printed."""
+    arrs = tess(64, 32)
+    R.load_scene_arrays(*arrs)
+    assert R.set_traversal(-1) == R.CERTIFIED
+    o = OracleScene.from_arrays(*arrs)
+    st, ost, nd, same8 = render_vs_oracle(R, o, 200, 160, 8, 8)
+    print(f"certified, 65 536 triangles: {nd} pixels differ; {st.node_visits / st.rays:.2f} node fetches + {st.prim_tests / st.rays:.2f} triangle tests per ray "
+          f"(reference's walk: {ost.node_visits / ost.rays:.2f} + {ost.prim_tests / ost.rays:.2f}); of {st.hits} hits {st.cert_chain} took the ancestor chain, "
+          f"{st.cert_fallback} rays the reference's walk")
+    assert nd == 0 and same8 and (st.rays, st.hits) == (ost.rays, ost.hits)
+    assert st.cert_chain < 0.05 * st.hits and st.cert_fallback < 0.001 * st.hits
+    # the same frame through the reference's own tree (packed layout) and with the certified walk cut into single segments
+    R.set_traversal(R.PACKED)
+    st2, _, nd2, _ = render_vs_oracle(R, o, 200, 160, 8, 8)
+    assert nd2 == 0 and (st2.node_visits, st2.prim_tests) == (ost.node_visits, ost.prim_tests)
+    R.set_traversal(-1)
+    R.update_resolution(200, 160); R.set_config(segments_per_launch=1, collect_stats=False); R.render_frame()
+    _, orad, _ = o.render(default_camera(), 200, 160, 8, max_depth=8)
+    assert (bits(R.read_image(rgb8=False)[1]) == bits(orad)).all()
+    R.set_config(segments_per_launch=0)
+
+
+@pytest.mark.gpu
+def test_certified_walk_sends_what_it_cannot_prove_through_the_references_walk(R):
+    """The three ways out of the proof, each forced: (1) EVERY hit a tie - the scene holds every triangle twice, with another
+    colour, so the reference's "first visited wins" decides every pixel; (2) ray origins outside the range the boxes are padded
+    for - a camera 60 units away; (3) forced onto a small scene.  Frames must be the oracle's; the counters show the path taken."""
+    p = ptmi.HostScene.load(os.path.join(SCENES, "cbox.obj"), 1, False).prims()
+    n = len(p["type"])
+    dup = {k: np.concatenate([p[k], p[k]]) for k in ("type", "verts", "normal", "bsdf", "Le")}
+    dup["bsdf"][n:] = dup["bsdf"][n:][:, ::-1] * 0.5            # the copies are darker and colour-swapped
+    arrs = (dup["type"], dup["verts"], dup["normal"], dup["bsdf"], dup["Le"])
+    R.load_scene_arrays(*arrs)
+    o = OracleScene.from_arrays(*arrs)
+    try:
+        assert R.set_traversal(R.CERTIFIED) == R.CERTIFIED
+        st, ost, nd, same8 = render_vs_oracle(R, o, 96, 80, 6, 5)
+        print(f"every triangle twice: {nd} pixels differ; {st.cert_fallback} of {st.hits} hits decided by the reference's walk")
+        assert nd == 0 and same8 and st.cert_fallback >= 0.99 * st.hits
+        R.set_traversal(-1); R.set_config(fast_tree=True)             # the uncertified fast walk: the smaller-slot rule, reported
+        _, _, nd_fast, _ = render_vs_oracle(R, o, 96, 80, 6, 5)
+        print(f"   the same through the fast tree without the certificate: {nd_fast} pixels differ")
+        R.set_config(fast_tree=False)
+        # (2) a far camera on the plain scene
+        path = os.path.join(SCENES, "cbox.obj")
+        R.load_scene(path, 3, False)
+        o = OracleScene.load(path, 3, False)
+        assert R.set_traversal(R.CERTIFIED) == R.CERTIFIED
+        cam = ptmi.default_camera(); cam.origin[:] = (0.5, 3.0, 60.0)
+        ocam = default_camera(); ocam.origin[:] = (0.5, 3.0, 60.0)
+        R.set_camera(cam)
+        st, ost, nd, same8 = render_vs_oracle(R, o, 96, 80, 6, 5, cam=ocam)
+        print(f"camera 60 units away: {nd} pixels differ; {st.cert_fallback} rays through the reference's walk ({96 * 80 * 6} camera rays)")
+        assert nd == 0 and same8 and st.cert_fallback >= 0.9 * 96 * 80 * 6 * 0.1
+        # (3) the default camera on the same small scene
+        R.set_camera(ptmi.default_camera())
+        st, ost, nd, same8 = render_vs_oracle(R, o, 128, 96, 8, 8)
+        print(f"cbox subdivided (2048 triangles), certified: {nd} pixels differ; chain {st.cert_chain}, reference's walk {st.cert_fallback} of {st.hits} hits")
+        assert nd == 0 and same8
+    finally:
+        R.set_camera(ptmi.default_camera()); R.set_traversal(-1); R.set_config(fast_tree=False, collect_stats=False)
+
+
 @pytest.mark.gpu
 def test_fast_tree_on_a_quad_scene_keeps_the_exact_walk(R):
     path = os.path.join(SCENES, "cbox_quads.obj")

@@ -20,7 +20,8 @@ for share in shares:
     for v in variants:
         fast, leaf, ctrav, top, seg = v.split(":")
         info = r.debug_set_fast_tree(int(leaf), float(ctrav), 1.0, int(top)) if int(fast) else {}
-        r.set_config(spp=spp, max_depth=8, segments_per_launch=int(seg), collect_stats=True, fast_tree=bool(int(fast)))
+        r.set_traversal(6 if int(fast) == 2 else -1)          # fast 2 = the certified (exact) form of the fast walk
+        r.set_config(spp=spp, max_depth=8, segments_per_launch=int(seg), collect_stats=True, fast_tree=int(fast) == 1)
         r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
         st = r.render_frame()
         rad = r.read_image(rgb8=False)[1]
@@ -34,4 +35,4 @@ for share in shares:
             t0 = time.perf_counter(); s2 = r.render_frame(); best = min(best, time.perf_counter() - t0)
         n = 2048 * (2048 // share) * spp
         print(f"1/{share} {v:>16}: {best*1e3:8.2f} ms = {n/best/1e6:7.1f} Msamples/s, {s2.bounce_launches} launches; nodes/ray {st.node_visits/st.rays:.2f} "
-              f"(LDS {st.top_node_visits/max(st.node_visits,1):.2f}) tests/ray {st.prim_tests/st.rays:.2f}; vs first variant: {nd} px differ, RMSE {rmse:.2e}; {info}", flush=True)
+              f"(LDS {st.top_node_visits/max(st.node_visits,1):.2f}) tests/ray {st.prim_tests/st.rays:.2f}; vs first variant: {nd} px differ, RMSE {rmse:.2e}; cert chain {st.cert_chain} fallback {st.cert_fallback} of {st.hits} hits; {info}", flush=True)
