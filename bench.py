@@ -312,6 +312,7 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     if own_walk:
         r.set_config(fast_tree=fast)
         st_walk = r.render_frame()
+    bytes_per_sample = algorithmic_bytes_per_sample(st_counts, r.scene_info()["n_quads"] > 0)
     r.set_config(collect_stats=False)
     if warmup:
         run_steps(warmup, False, pipelined)

@@ -197,7 +197,8 @@ def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
     o = OracleScene.load(path, sub, conv)
     try:
         assert R.set_packed_min_nodes(16) > R.scene_info()["n_bvh_nodes"]          # pairs: root + padding + 2 per inner node
-        assert R.set_traversal(-1) == R.PACKED
+        # the automatic choice for a triangle scene with the fast tree built is the certified walk; this test is about the packed one
+        assert R.set_traversal(-1) in (R.PACKED, R.CERTIFIED) and R.set_traversal(R.PACKED) == R.PACKED
         if sampling:
             grids = synthetic_radiosity_grids(o.n_prims, seed=sampling)
             R.set_radiosity_grids(grids); o.set_radiosity_grids(grids); o.set_mis_fraction(0.5)
@@ -215,7 +216,7 @@ def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
         for top in (0, 6, 64, 2048):                                    # how much of the tree is walked from LDS must not matter
             n_top, d_top = R.set_packed_top(top)
             assert n_top <= max(top, 0) and (n_top == 0) == (top < 4)
-            assert R.set_traversal(-1) == R.PACKED
+            assert R.set_traversal(R.PACKED) == R.PACKED
             R.update_resolution(W, H); R.set_config(collect_stats=True); st = R.render_frame()
             assert_same_image(*R.read_image(), orgb, orad, f"{name} packed, LDS top {top}")
             assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
