@@ -282,6 +282,7 @@ int ptmi_run_radiosity_solver(ptmi_ctx* c, const ptmi_radiosity_params* p, ptmi_
         if (stats) {
             stats->seconds = st.seconds; stats->form_factor_ms = st.form_factor_ms; stats->iteration_ms = st.iteration_ms;
             stats->grid_ms = st.grid_ms; stats->pairs = st.pairs; stats->rays = st.rays;
+            stats->cert_chain = st.cert_chain; stats->cert_fallback = st.cert_fallback; stats->walk = st.walk;
         }
     });
 }
@@ -573,6 +574,15 @@ int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, i
         }
         s.chooseTraversal();
         if (out_mode) *out_mode = s.d_nodes ? s.d_scene.traversal : -1;
+    });
+}
+
+int ptmi_debug_set_solver_walk(ptmi_ctx* c, int force_walk, int min_prims) {
+    return guarded([&] {
+        need(c != nullptr, "ctx is NULL");
+        need(force_walk == -1 || force_walk == 0 || (force_walk >= 2 && force_walk <= 4), "force_walk must be -1, 0, 2, 3 or 4");
+        need(min_prims >= 0, "min_prims must be >= 0");
+        c->app.radiosity.force_walk = force_walk; c->app.radiosity.cert_min_prims = min_prims;
     });
 }
 

@@ -72,6 +72,7 @@ struct DeviceScene {
     const uint4* wanc = nullptr;       // per reference leaf: its ancestors' pre-order node indices (leaf included), 4 per chunk, 0xffffffff pads
     const float4* wcert = nullptr;     // per fast-order triangle: (leaf box min, bits(first chunk << 5 | chunks of the leaf's list)) (leaf box max, 0)
     float w_big = 0.0f;                // the scene's largest |coordinate|
+    int w_cert_debug = 0;              // test hook of the solver's certified walk: 1 every blocked ray takes the ancestor chain, 2 the reference's walk
     const int* wfast_of_ref = nullptr; // reference leaf-order slot -> fast order
     float w_guard = 0.0f;              // the boxes are padded for ray origins with |coordinate| <= w_guard; others take the reference's walk
 };
@@ -188,7 +189,7 @@ struct RadiosityBuffers {
     unsigned long long* rays = nullptr;   // shadow rays cast (1 counter)
     int n = 0;
     int bvh_depth = 0;                 // > 30: the visibility walk keeps the reference's explicit stack and drop rule
-    int fast_tree = 0;                 // 1: the visibility walk goes through DeviceScene's fast tree (opt-in, triangle scenes)
+    int fast_tree = 0;                 // the visibility walk: 0 the reference's, 1 DeviceScene's fast tree (opt-in), 2 the certified walk
 };
 struct RadiosityParams {
     int num_iterations, mc_samples, use_monte_carlo, enable_filtering, use_bilateral;

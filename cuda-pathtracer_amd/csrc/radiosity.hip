@@ -166,7 +166,48 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
 // pair's own two hit within max_dist.  Same triangles, same test arithmetic (anyhit_prim's triangle form on the tree's own
 // 36-byte records), conservative boxes: the answer is the reference's unless the reference's own slab test drops, by rounding,
 // the box of a triangle that the ray does hit.  Stack: one 8-byte entry per tree level, entry e of lane l at stack[e * kBlock].
-__device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float max_dist, int load_a, int load_b) {
+//
+// CERT (the default for triangle scenes from RadiosityState::cert_min_prims = 256 primitives up): the reference's answer for every ray, by proof.
+//   "not blocked" needs none: the fast walk reaches every triangle whose hit point lies in range (conservative boxes), the
+//     reference's walk tests a subset of them with the same arithmetic.
+//   "blocked by triangle k at t": the reference tests k iff every box on the way from its root to k's leaf passes ITS slab
+//     test (anyhit_box - no closest-hit distance in it, so the visiting order does not matter).  One fetch decides that for
+//     almost every ray: the hit point Q = o + t d inside the LEAF's reference box by eps = 2^-20 (|o_a| + big) on all six
+//     faces puts it inside every ancestor's box by as much (boxes are nested), which is more than the slab arithmetic can be
+//     off by - t0' = fl(fl(lo - o) fl(1 / d)) lies within 3 * 2^-24 |lo - o| / |d| of the plane's true distance, Q_a' within
+//     4 * 2^-24 (|o_a| + big) of Q_a - so every entry distance comes out <= t <= max_dist and every exit distance >= t >= 1e-5.
+//     Needs |d_a| > 1e-8 (below that the reference replaces 1 / d by 1e8); otherwise, or within eps of a face: the exact
+//     anyhit_box over the leaf's ancestor list (wanc); a box of that list failing: the reference's own walk for this ray.
+template <bool CERT>
+__device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 lo, float4 hi, float t, f3 o, f3 d, float max_dist, int slot_a, int slot_b, unsigned int& chain) {
+    const f3 q = o + t * d;
+    const float big = sc.w_big;
+    const float ex = 9.5367431640625e-7f * (fabsf(o.x) + big), ey = 9.5367431640625e-7f * (fabsf(o.y) + big), ez = 9.5367431640625e-7f * (fabsf(o.z) + big);
+    const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
+    const bool slopes = fabsf(d.x) >= 1.4901161193847656e-8f && fabsf(d.y) >= 1.4901161193847656e-8f && fabsf(d.z) >= 1.4901161193847656e-8f;   // 2^-26 > 1e-8
+    if (inside && slopes && sc.w_cert_debug == 0) return true;
+    chain++;
+    const f3 inv = mk3(1.0f / (fabsf(d.x) > 1e-8f ? d.x : 1e-8f), 1.0f / (fabsf(d.y) > 1e-8f ? d.y : 1e-8f), 1.0f / (fabsf(d.z) > 1e-8f ? d.z : 1e-8f));
+    const uint32_t ref = __float_as_uint(lo.w);
+    uint32_t off = ref >> 5;
+    bool ok = true;
+    for (int left = (int)(ref & 31u); left > 0 && ok; left--, off++) {
+        const uint4 idx = sc.wanc[off];
+        const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];          // padding repeats the root
+            ok = ok && anyhit_box(sc.nodes[2 * (size_t)j], sc.nodes[2 * (size_t)j + 1], o, inv, max_dist);
+        }
+    }
+    if (ok && sc.w_cert_debug < 2) return true;
+    chain += 0x10000u;
+    return visibility_blocked<false, false>(sc, o, d, max_dist, slot_a, slot_b);
+}
+
+template <bool CERT>
+__device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float max_dist, int load_a, int load_b,
+                                                        int slot_a, int slot_b, unsigned int& chain) {
     const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
     const uint32_t octinv = wide_octinv(inv);
     int sp = 0;
@@ -203,7 +244,12 @@ __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, u
             const float t = f * dot(edge2, qq);
             float m = min3_raw(m1, v, 1.0f - (u + v));
             m = min_raw(m, t - 1e-5f);
-            if ((m >= 0.0f) & (t <= max_dist)) return true;
+            if ((m >= 0.0f) & (t <= max_dist)) {
+                if (!CERT) return true;
+                // (fetching the leaf box together with the triangle record, before the test: no gain - n = 8192: 84.0 vs 84.4 ms)
+                const float4 c_lo = sc.wcert[2 * (size_t)k], c_hi = sc.wcert[2 * (size_t)k + 1];
+                return certified_blocked<CERT>(sc, c_lo, c_hi, t, o, d, max_dist, slot_a, slot_b, chain);
+            }
         }
         g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
     }
@@ -246,9 +292,9 @@ __device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __res
 // the sample loop and F_ij of calculate_form_factors_mc_kernel (form_factors.h:259-365) for one surviving pair
 // The emitter's record is read again for every sample (it is L1-resident, and only the sample's first lines use it): its
 // 13 - 18 registers do not have to live through the visibility walk, where the kernel is short of them (7 waves per SIMD).
-template <bool HAS_QUADS, bool DEEP, bool RAD0, bool WIDE>
+template <bool HAS_QUADS, bool DEEP, bool RAD0, int WIDE>
 __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, int i, const Geom& gi, const float4* __restrict__ geo, int j, int slot_i, int slot_j,
-                                         int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays) {
+                                         int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays, unsigned int& chain) {
     float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
     int valid_samples = 0;
     for (int s = 0; s < actual_samples; ++s) {
@@ -268,7 +314,8 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, i
         const f3 ro = p_i + 1e-4f * gi.normal;
         const f3 rd = unit_vector(sample_dir);                                  // Ray's constructor normalises again (ray.h:9-12)
         rays++;
-        const bool blocked = WIDE ? visibility_blocked_wide(sc, wstack, ro, rd, r - 2e-4f, i, j) : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j);
+        const bool blocked = WIDE ? visibility_blocked_wide<WIDE == 2>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
+                                  : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j);
         if (!blocked) {
             visibility_sum += 1.0f; cos_i_sum += cos_theta_i; cos_j_sum += cos_theta_j; dist_sum += r;
             valid_samples++;
@@ -295,8 +342,9 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, i
 }
 
 // calculate_form_factors_kernel (form_factors.h:368-415) after its culling tests
-template <bool HAS_QUADS, bool DEEP, bool WIDE>
-__device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, int i, int j, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays) {
+template <bool HAS_QUADS, bool DEEP, int WIDE>
+__device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, int i, int j, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays,
+                                          unsigned int& chain) {
     const f3 vec_ij = gj.centroid - gi.centroid;
     const float r = length(vec_ij);
     const f3 dir_ij = div_scalar(vec_ij, r);
@@ -305,7 +353,8 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, 
     const f3 ro = gi.centroid + 1e-4f * gi.normal;
     const f3 rd = unit_vector(dir_ij);
     rays++;
-    if (WIDE ? visibility_blocked_wide(sc, wstack, ro, rd, r - 2e-4f, i, j) : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
+    if (WIDE ? visibility_blocked_wide<WIDE == 2>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
+             : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
     const float ff = (float)((double)(cos_theta_i * cos_theta_j * gj.area) / (PTMI_PI_D * (double)r * (double)r));
     return fmaxf(0.0f, ff);
 }
@@ -317,10 +366,11 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, 
 #ifndef PTMI_FF_WIDE_WAVES
 #define PTMI_FF_WIDE_WAVES 6
 #endif
-// WIDE: the visibility walk goes through the opt-in fast tree (visibility_blocked_wide); its node test wants ~80 registers, so
-// that build is bounded to 6 waves per SIMD (n = 8192: 4 / 5 / 6 waves 78.8 / 74.9 / 70.4 ms; the exact walk: 131.8) and keeps its
-// per-lane stack in dynamic LDS (depth x 2 KB per workgroup)
-template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0, bool WIDE>
+// WIDE (1: the opt-in fast tree, 2: the certified walk - the default from 256 triangles up): the visibility walk goes through
+// visibility_blocked_wide; its node test wants ~80 registers, so that build is bounded to 6 waves per SIMD (n = 8192, fast tree:
+// 4 / 5 / 6 waves 78.8 / 74.9 / 70.4 ms; certified: 5 / 6 / 7 waves 84.1 / 84.4 / 83.5 ms; the reference's walk: 130.4) and keeps
+// its per-lane stack in dynamic LDS (depth x 2 KB per workgroup)
+template <bool MC, bool HAS_QUADS, bool DEEP, bool RAD0, int WIDE>
 __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_form_factors(DeviceScene sc, RadiosityBuffers rb, int n_samples,
                                                             const uint32_t* __restrict__ jump) {
     extern __shared__ uint2 ff_wstack[];
@@ -341,7 +391,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_fo
     if (RAD0) { radg[3 * tid] = 0.0f; radg[3 * tid + 1] = 0.0f; radg[3 * tid + 2] = 0.0f; }
     if (tid == 0) { q_n = 0; rays_wg = 0u; }
     __syncthreads();
-    unsigned int rays = 0u;
+    unsigned int rays = 0u, chain = 0u;           // chain: certified walk - rays that took the ancestor chain (low half) / the reference's walk (high half)
 
     for (int base = 0; base < n; base += kBlock) {
         const int j = base + tid;
@@ -393,8 +443,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_fo
             if (have) {
                 const int slot_j = rb.slot_of[e.x];
                 float F;
-                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0, WIDE>(sc, wstack, i, gi, rb.geo, e.x, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays);
-                else F = p2p_pair<HAS_QUADS, DEEP, WIDE>(sc, wstack, i, e.x, gi, load_geom(rb.geo, e.x), slot_i, slot_j, rays);
+                if (MC) F = mc_pair<HAS_QUADS, DEEP, RAD0, WIDE>(sc, wstack, i, gi, rb.geo, e.x, slot_i, slot_j, e.y, rng, xyz(rb.radiosity[e.x]), counts, radg, rays, chain);
+                else F = p2p_pair<HAS_QUADS, DEEP, WIDE>(sc, wstack, i, e.x, gi, load_geom(rb.geo, e.x), slot_i, slot_j, rays, chain);
                 row[e.x] = F;
             }
             __syncthreads();
@@ -406,6 +456,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_fo
     rb.rad_grid[(size_t)i * kGridSize + tid] = RAD0 ? make_float4(radg[3 * tid], radg[3 * tid + 1], radg[3 * tid + 2], 0.0f)
                                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (tid == 0 && rb.rays) atomicAdd(rb.rays, (unsigned long long)rays_wg);
+    if (WIDE == 2 && chain && rb.rays) { atomicAdd(rb.rays + 1, (unsigned long long)(chain & 0xffffu)); atomicAdd(rb.rays + 2, (unsigned long long)(chain >> 16)); }
 }
 
 // radiosity_iteration_kernel (form_factors.h:441-465): one thread per receiver, ascending j - the float sum is a
@@ -747,15 +798,20 @@ __global__ __launch_bounds__(kBlock) void ptmi_cdf_records(const void* __restric
 template <bool MC, bool Q_, bool D_>
 void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
     if constexpr (!Q_ && !D_) {
-        if (rb.fast_tree && sc.wnodes) {                   // the opt-in fast tree for the visibility walk
-            const size_t lds = (size_t)sc.w_depth * kBlock * sizeof(uint2);
-            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, true>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
-            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, true>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+        const size_t lds = (size_t)sc.w_depth * kBlock * sizeof(uint2);
+        if (rb.fast_tree == 1 && sc.wnodes) {              // the opt-in fast tree for the visibility walk, no certificate
+            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            return;
+        }
+        if (rb.fast_tree == 2 && sc.wnodes && sc.wcert && sc.wanc) {   // the certified walk: the reference's answers, through the fast tree
+            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
             return;
         }
     }
-    if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
-    else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, false, false>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+    if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, true, 0>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
+    else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, D_, false, 0>), grid, dim3(kBlock), 0, s, sc, rb, n_samples, jump);
 }
 template <bool MC>
 void launch_ff1(bool quads, bool deep, bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples,

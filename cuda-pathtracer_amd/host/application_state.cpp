@@ -484,9 +484,19 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         return p;
     };
     d.n = n; d.bvh_depth = scene.bvh_depth;
-    if (fast_tree && !scene.num_quads && scene.bvh_depth <= 30) {          // opt-in: built on first use, as for the render path
-        if (!scene.fastReady()) scene.buildFast();
-        d.fast_tree = 1;
+    // the visibility walk: 0 the reference's own (stackless over its tree), 1 the opt-in fast tree (AppConfig::fast_tree), 2 the
+    // certified walk - the fast tree + a per-ray proof that the reference's any-hit walk gives the same answer (radiosity.hip:
+    // certified_blocked) - the default for triangle scenes from cert_min_prims primitives up; trees are built on first use
+    {
+        const bool can = !scene.num_quads && scene.bvh_depth <= 30;
+        int walk = 0;
+        if (can && fast_tree) walk = 1;
+        else if (can && (force_walk >= 2 || (force_walk < 0 && scene.certified_default && n >= cert_min_prims))) walk = 2;
+        if (walk) {
+            if (!scene.fastReady()) scene.buildFast();
+            if (walk == 2 && !(scene.d_scene.wcert && scene.d_scene.wanc)) walk = 0;
+        }
+        d.fast_tree = walk;
     }
     d.geo = (const float4*)upload(geo.data(), geo.size() * sizeof(float4), "d_radiosity_geo");
     d.slot_of = (const int*)upload(slot_of.data(), slot_of.size() * sizeof(int), "d_radiosity_slot_of");
@@ -497,8 +507,8 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     d.form_factors = (float*)upload(nullptr, (size_t)n * (size_t)n * sizeof(float), "d_form_factors");
     d.grid = (unsigned int*)upload(nullptr, (size_t)n * kGridSize * sizeof(unsigned int), "d_radiosity_grid_counts");
     d.rad_grid = (float4*)upload(nullptr, (size_t)n * kGridSize * sizeof(float4), "d_radiosity_grids");
-    d.rays = (unsigned long long*)upload(nullptr, sizeof(unsigned long long), "d_radiosity_rays");
-    PTMI_HIP(hipMemset(d.rays, 0, sizeof(unsigned long long)));
+    d.rays = (unsigned long long*)upload(nullptr, 3 * sizeof(unsigned long long), "d_radiosity_rays");   // rays, certified: chains, fallbacks
+    PTMI_HIP(hipMemset(d.rays, 0, 3 * sizeof(unsigned long long)));
 
     RadiosityParams prm;
     prm.num_iterations = num_iterations; prm.mc_samples = mc_samples; prm.use_monte_carlo = use_monte_carlo ? 1 : 0;
@@ -513,7 +523,9 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     hipEvent_t* ev = events.e;
     for (int k = 0; k < 4; k++) PTMI_HIP(hipEventCreate(&ev[k]));
     PTMI_HIP(hipEventRecord(ev[0], stream));
-    launch_form_factors(scene.d_scene, d, prm, d_jump, stream);                       // :726-741
+    DeviceScene ff_scene = scene.d_scene;
+    ff_scene.w_cert_debug = force_walk == 3 ? 1 : force_walk == 4 ? 2 : 0;
+    launch_form_factors(ff_scene, d, prm, d_jump, stream);                       // :726-741
     PTMI_HIP(hipGetLastError());
     PTMI_HIP(hipEventRecord(ev[1], stream));
     for (int it = 0; it < num_iterations; ++it) launch_radiosity_iteration(d, it & 1, stream);   // :748-771
@@ -547,9 +559,9 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         PTMI_HIP(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->iteration_ms = ms;
         PTMI_HIP(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->grid_ms = ms;
         stats->pairs = (uint64_t)n * (uint64_t)n;
-        unsigned long long rays = 0;
-        PTMI_HIP(hipMemcpy(&rays, d.rays, sizeof rays, hipMemcpyDeviceToHost));
-        stats->rays = rays;
+        unsigned long long rays[3] = {0, 0, 0};
+        PTMI_HIP(hipMemcpy(rays, d.rays, sizeof rays, hipMemcpyDeviceToHost));
+        stats->rays = rays[0]; stats->cert_chain = rays[1]; stats->cert_fallback = rays[2]; stats->walk = d.fast_tree;
     }
 }
 

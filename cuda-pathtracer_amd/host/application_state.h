@@ -130,10 +130,12 @@ private:
 // copy of the 4364-byte Primitive records; no n^2 curandStates (streams are derived in the kernel); the reference's
 // per-iteration update_radiosity_grid (+ filter), whose result every later iteration overwrites, runs once at the end;
 // radiosity_history (no reader in the reference outside primitive.h) is not kept.
-struct RadiosityStats { double seconds = 0, form_factor_ms = 0, iteration_ms = 0, grid_ms = 0; uint64_t pairs = 0, rays = 0; };
+struct RadiosityStats { double seconds = 0, form_factor_ms = 0, iteration_ms = 0, grid_ms = 0; uint64_t pairs = 0, rays = 0, cert_chain = 0, cert_fallback = 0; int walk = 0; };
 struct RadiosityState {
     int num_iterations = 10, mc_samples = 64;        // application_state.h:208
     bool use_monte_carlo = true, is_calculated = false;
+    int force_walk = -1;                             // new (debug): -1 automatic, 0 the reference's visibility walk, 2 the certified walk (3 / 4: its chain / its fallback for every blocked ray)
+    int cert_min_prims = 256;                        // new: automatic choice takes the certified walk from this many triangles up
     RadiosityBuffers d;                              // device arrays (owned)
     int final_unshot = 0;                            // which d.unshot[] holds the last iteration's unshot radiosity
     // results on the host, load order (filled by runSolver)

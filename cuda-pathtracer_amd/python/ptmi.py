@@ -29,6 +29,7 @@ EXPORTS = [
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
     "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
     "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_dist_comm_count", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect", "ptmi_host_fast_tree_stats",
+    "ptmi_debug_set_solver_walk",
 ]
 
 
@@ -55,7 +56,7 @@ class RadiosityParams(C.Structure):
 
 class RadiosityStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("form_factor_ms", C.c_double), ("iteration_ms", C.c_double), ("grid_ms", C.c_double),
-                ("pairs", C.c_uint64), ("rays", C.c_uint64)]
+                ("pairs", C.c_uint64), ("rays", C.c_uint64), ("cert_chain", C.c_uint64), ("cert_fallback", C.c_uint64), ("walk", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -120,6 +121,7 @@ def lib():
         L.ptmi_debug_rng.argtypes = [vp, C.c_uint64, C.c_int, vp, C.c_int, vp]
         L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.ptmi_debug_set_traversal.argtypes = [vp, C.c_int, C.c_int, ip]
+        L.ptmi_debug_set_solver_walk.argtypes = [vp, C.c_int, C.c_int]
         L.ptmi_debug_rcp_check.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.ptmi_host_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.ptmi_host_scene_from_arrays.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.POINTER(vp)]
@@ -511,6 +513,10 @@ class Renderer:
         m = C.c_int(-1)
         self._ck(self.L.ptmi_debug_set_traversal(self.h, int(force_mode), int(sweep_max_prims), C.byref(m)))
         return m.value
+
+    def set_solver_walk(self, force_walk=-1, min_prims=256):
+        """Visibility walk of the next radiosity solve: -1 automatic, 0 the reference's tree, 2 certified (identical form factors)."""
+        self._ck(self.L.ptmi_debug_set_solver_walk(self.h, int(force_walk), int(min_prims)))
 
     def set_packed_min_nodes(self, min_nodes=8192):
         """Smallest tree (BVH nodes) that gets the packed layout of traversal mode PACKED; returns the record positions built."""

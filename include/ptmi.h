@@ -139,6 +139,10 @@ typedef struct {
     double   form_factor_ms, iteration_ms, grid_ms;
     uint64_t pairs;               /* n_prims^2 */
     uint64_t rays;                /* shadow rays cast by the form-factor kernel */
+    uint64_t cert_chain;          /* certified walk: blocked rays whose proof needed the exact slab tests over the blocker's ancestors */
+    uint64_t cert_fallback;       /* certified walk: rays that went through the reference's own walk */
+    int      walk;                /* the visibility walk used: 0 the reference's tree, 1 the opt-in fast tree (ptmi_config.fast_tree),
+                                   * 2 certified (fast tree + per-ray proof: the reference's answers; default from 256 triangles up) */
 } ptmi_radiosity_stats;
 
 /* ---- lifetime ------------------------------------------------------------ */
@@ -320,6 +324,12 @@ int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int ro
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
 int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int* out_mode);
+/* The visibility walk of the radiosity pre-pass's form-factor kernel: force_walk -1 = automatic (certified from min_prims
+ * triangles up, default 256; else the reference's), 0 = the reference's own tree, 2 = certified (the fast tree + a per-ray
+ * proof that the reference's any-hit walk answers the same; triangle scenes no deeper than 30; test hooks: 3 / 4 = certified
+ * with every blocked ray sent through the proof's second stage / through the reference's own walk).  Form factors are identical
+ * either way; ptmi_config.fast_tree (no proof, tolerance mode) takes precedence.  Applies to the next ptmi_run_radiosity_solver. */
+int ptmi_debug_set_solver_walk(ptmi_ctx*, int force_walk, int min_prims);
 /* The packed layout of traversal mode 4 is built for scenes that do not fit LDS, have at least min_nodes BVH nodes (default
  * 8192), a tree no deeper than 62 and no leaf of more than 7 primitives.  Applies to the loaded scene at once and to later
  * loads; n_positions (may be NULL) receives the number of record positions built (0 = none).  Results do not depend on it. */

@@ -244,6 +244,42 @@ def test_radiosity_solver_through_the_fast_tree(R, sub):
         R.set_config(fast_tree=False)
 
 
+@pytest.mark.gpu
+def test_radiosity_solver_certified_walk_is_the_references(R):
+    """The solver's default visibility walk from 256 triangles up: the fast tree + a proof per blocked ray that the reference's
+    any-hit walk (form_factors.h:143-208) is blocked too (radiosity.hip: certified_blocked).  The whole form-factor matrix must
+    equal the one the reference's own walk gives - 2048 primitives Monte-Carlo and point-to-point (centroid rays between the
+    box's walls are axis-parallel: the proof's first stage does not apply, the chain of exact slab tests decides), and with
+    every blocked ray forced through the chain (3) and through the reference's walk (4)."""
+    path = os.path.join(SCENES, "cbox.obj")
+    R.load_scene(path, 3, False)
+    try:
+        for mc in (1, 0):
+            R.set_solver_walk(0)
+            st0 = R.run_radiosity_solver(use_monte_carlo=mc, num_iterations=2)
+            want = R.radiosity_solution()
+            assert st0.walk == 0 and st0.cert_chain == 0
+            for walk in (-1, 3, 4):
+                R.set_solver_walk(walk)
+                st = R.run_radiosity_solver(use_monte_carlo=mc, num_iterations=2)
+                got = R.radiosity_solution()
+                print(f"certified solver walk {walk}, mc {mc}: {st.rays} rays, {st.cert_chain} chains, {st.cert_fallback} fallbacks, "
+                      f"form factors {st.form_factor_ms:.2f} ms (reference's walk {st0.form_factor_ms:.2f} ms)")
+                assert st.walk == 2 and st.rays == st0.rays
+                for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"):
+                    assert (bits(got[k]) == bits(want[k])).all(), (walk, mc, k)
+                if walk == 3: assert st.cert_chain > 0 and st.cert_fallback == 0
+                if walk == 4: assert st.cert_fallback == st.cert_chain > 0
+                if walk == -1: assert st.cert_fallback <= st.cert_chain < st.rays // 10
+        R.set_solver_walk(-1, 1 << 20)
+        assert R.run_radiosity_solver(num_iterations=1).walk == 0                  # below the threshold: the reference's walk
+        R.load_scene(os.path.join(SCENES, "cbox_quads.obj"), 3, False)             # quads: no fast tree
+        R.set_solver_walk(2)
+        assert R.run_radiosity_solver(num_iterations=1).walk == 0
+    finally:
+        R.set_solver_walk(-1)
+
+
 def render_vs_oracle(R, o, W, H, spp, depth, cam=None):
     R.update_resolution(W, H)
     R.set_config(spp=spp, max_depth=depth, collect_stats=True, segments_per_launch=0)

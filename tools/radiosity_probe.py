@@ -1,4 +1,6 @@
-"""Timing probe for the radiosity pre-pass: python tools/radiosity_probe.py [sub ...] [--oracle] [--p2p] [--samples N]
+"""Timing probe for the radiosity pre-pass: python tools/radiosity_probe.py [sub ...] [--oracle] [--p2p] [--samples N] [--fast | --walk W]
+   --fast : the visibility walk through the opt-in fast tree, no certificate;  --walk 0 : the reference's own walk, --walk 2 : certified
+           (default: automatic = certified from 256 triangles up)
    --check-profile FILE : only check that FILE (profiles/rNN_pmc_radiosity.json) was taken from the solver kernels that are built
                           now (stamps of ptmi_buildinfo: the library, or the sources compiled into build/radiosity.o); exit 1 if not"""
 import os, sys, time
@@ -24,12 +26,13 @@ fast = "--fast" in sys.argv            # the visibility walk through the opt-in 
 scene = os.path.join(ROOT, "tests", "golden", "scenes", "cbox.obj")
 R = ptmi.Renderer(0)
 R.set_config(fast_tree=fast)
+if "--walk" in sys.argv: R.set_solver_walk(int(sys.argv[sys.argv.index("--walk") + 1]))
 for sub in subs:
     R.load_scene(scene, sub, False)
     n = R.scene_info()["n_prims"]
     for rep in range(2):
         t = time.time(); st = R.run_radiosity_solver(**kw); wall = time.time() - t
-    print(f"sub {sub}: n={n} pairs={st.pairs} rays={st.rays} | form factors {st.form_factor_ms:.2f} ms "
+    print(f"sub {sub}: n={n} walk={st.walk} chains={st.cert_chain} fallbacks={st.cert_fallback} pairs={st.pairs} rays={st.rays} | form factors {st.form_factor_ms:.2f} ms "
           f"({st.rays / st.form_factor_ms / 1e3:.1f} Mrays/s, {st.pairs / st.form_factor_ms / 1e3:.1f} Mpairs/s) | "
           f"iterations {st.iteration_ms:.2f} ms | grids {st.grid_ms:.2f} ms | device {st.seconds * 1e3:.2f} ms | wall {wall * 1e3:.1f} ms", flush=True)
     if want_oracle:
