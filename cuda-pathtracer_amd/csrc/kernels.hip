@@ -847,8 +847,13 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // hit if (1) it reaches k*'s leaf and (2) no second triangle is hit at exactly t*.  (1): the reference enters a node when
 // `!(min(t_exit, closest_t) < t_entry)` holds for it and all its ancestors, closest_t being whatever it is at that moment -
 // never below the final t*; the test is monotone in closest_t, so if every ancestor of k*'s leaf (leaf included) passes
-// with closest_t = t* it passes in the reference: a VERIFY phase evaluates exactly these ~20 slab tests (box_hit, the exact
-// walk's arithmetic) from a per-leaf list of ancestor node indices, four nodes per step, fetched in parallel - not a chain.
+// with closest_t = t* it passes in the reference.  One fetch (the leaf's box, see VERIFY below) shows that for 99.7 % of the
+// hits; the rest evaluate these slab tests themselves (box_hit, the exact walk's arithmetic) from a per-leaf list of ancestor
+// node indices, leaf first, four nodes per step fetched in parallel, until a box holds the hit point with the margin - mostly
+// the parent or grandparent (1 M triangles: walking the whole list instead, root first: c5tile 1 455 -> 1 553 Msamples/s).
+// Measured and dropped: a certificate from the triangle's OWN bounds when the hit is accepted (no fetch; proves 97.3 % of the
+// hits): 1 515 against 1 553 - the leaf-box fetch rides on the SHADE step's latency anyway; 64-byte triangle records carrying
+// the leaf box (one line for test and certificate): 946.
 // (2): every triangle hit at t* is tested by the fast walk too, so a tie shows as `t == closest_t` there.  A ray for which
 // (1) or (2) cannot be shown - a grazed box, a shared edge, an origin outside the range the boxes were padded for - is walked
 // again by the reference's own walk (intersect_lane) inside this kernel: about one ray in 10^9.  No hit at all needs no
@@ -906,11 +911,57 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     while (true) {
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_prim = __popcll(__ballot(phase == PH_PRIM));
-        const int c_shade = __popcll(__ballot(phase == PH_SHADE));
-        const int c_verify = CERT ? __popcll(__ballot(phase == PH_VERIFY)) : 0;
-        if (c_node + c_prim + c_shade + c_verify == 0) break;
-        if (CERT && c_verify > 0 && c_verify >= c_node && c_verify >= c_prim && c_verify >= c_shade) {
-            if (phase == PH_VERIFY) {
+        // a lane whose hit has to be proven (VERIFY) votes with the SHADE lanes and takes one proof step right before that
+        // phase's work - for almost every hit the only one (the leaf-box fetch).  As a phase of its own (round 3's first form)
+        // the proof cost a wave iteration per ray and its stragglers waited for a majority: c5tile 1 407 -> 1 455 Msamples/s
+        const int c_shade = __popcll(__ballot(phase == PH_SHADE || (CERT && phase == PH_VERIFY)));
+        if (c_node + c_prim + c_shade == 0) break;
+        if (c_node >= c_prim && c_node >= c_shade) {
+            if (phase == PH_NODE) {
+                if ((g_bits & 0xffu) == 0u) { sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y; }
+                const int bit = 31 - __clz((int)(g_bits & 0xffu));
+                g_bits ^= 1u << bit;
+                const uint32_t child = (uint32_t)bit ^ octinv;
+                const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
+                if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
+                uint4 q0, q1, q2, q3, q4, q5, q6;
+                if ((int)ni < n_top) {
+                    // explicit address spaces: left generic, the two branches are merged into ONE flat_load through a selected pointer
+                    const LdsU4* q = top_lds + 8 * ni;
+                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
+                    if (STATS) cn.top_visits++;
+                } else {
+                    const GlobalU4* q = wnodes_g + 8 * (size_t)ni;
+                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
+                }
+                if (STATS) cn.node_visits++;
+                const WideStep st = wide_node_test(q0, q1, q2, q3, q4, q5, q6, p.o, inv, octinv, t_min, closest_t);
+                g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
+                t_base = st.tri_base; t_mask = st.tris;
+                if (t_mask) phase = PH_PRIM;
+                else if ((g_bits & 0xffu) == 0u && sp == 0) phase = after_walk();
+            }
+        } else if (c_prim >= c_shade) {
+            if (phase == PH_PRIM) {
+                const int k = (int)t_base + __ffs((int)t_mask) - 1;
+                t_mask &= t_mask - 1u;
+                if (STATS) cn.prim_tests++;
+                const f3p* r = reinterpret_cast<const f3p*>(a.sc.wprims) + 3 * (size_t)k;
+                const f3p r0 = r[0], r1 = r[1], r2 = r[2];
+                const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r1.x, r1.y, r1.z), e2 = mk3(r2.x, r2.y, r2.z);
+                float tt = 0.0f;
+                const bool ok = mt_hit(v0, e1, e2, p.o, p.d, 1e-8f, t_lo, tt);
+                if (ok) {
+                    if (tt < closest_t) { closest_t = tt; slot_hit = k; }
+                    else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
+                        if (CERT) need_exact = true;                       // a tie: let the reference's walk decide
+                        else if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
+                    }
+                }
+                if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : after_walk();
+            }
+        } else {
+            if (CERT && phase == PH_VERIFY) {
                 if (!need_exact && v_left < 0) {
                     // ONE fetch: the box of the hit triangle's leaf in the reference's tree.  Boxes are nested, so if the hit point
                     // Q = o + t* d lies inside the LEAF's box by eps on every face, it lies inside every ancestor's by at least
@@ -944,12 +995,26 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                         const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];      // padding repeats the root
                         n0[c] = a.sc.nodes[2 * (size_t)j]; n1[c] = a.sc.nodes[2 * (size_t)j + 1];
                     }
-                    bool ok = true;
+                    // from the leaf upwards: a box that holds Q with the margin settles all boxes above it (nested) - usually the
+                    // leaf's parent or grandparent; below it every box has to pass the reference's own slab test
+                    const f3 q = p.o + closest_t * p.d;
+                    const float big = a.sc.w_big;
+                    const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + big), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + big),
+                                ez = 9.5367431640625e-7f * (fabsf(p.o.z) + big);
+                    const float slopes = min3_raw(fabsf(p.d.x), fabsf(p.d.y), fabsf(p.d.z)) - 8.673617379884035e-19f;
+                    bool proven = false, failed = false;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) ok = ok && box_hit(n0[c], n1[c], p.o, inv, t_min, closest_t);
+                    for (int c = 0; c < 4; c++) {
+                        const float mx = min3_raw(q.x - n0[c].x - ex, n1[c].x - q.x - ex, slopes);
+                        const float my = min3_raw(q.y - n0[c].y - ey, n1[c].y - q.y - ey, q.z - n0[c].z - ez);
+                        const bool holds = min3_raw(mx, my, n1[c].z - q.z - ez) >= 0.0f;
+                        const bool passes = box_hit(n0[c], n1[c], p.o, inv, t_min, closest_t);
+                        failed = failed || (!proven && !holds && !passes);
+                        proven = proven || holds;
+                    }
                     if (STATS) cn.node_visits += 4;
-                    if (!ok) need_exact = true;
-                    else if (v_left == 0) phase = PH_SHADE;
+                    if (failed) need_exact = true;
+                    else if (proven || v_left == 0) phase = PH_SHADE;
                 }
                 if (need_exact) {                                      // the reference's walk itself, for this ray only
                     float t_ref = 0.0f; int slot_ref = -1;
@@ -961,50 +1026,6 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     if (STATS) cn.cert_fallback++;
                 }
             }
-        } else if (c_node >= c_prim && c_node >= c_shade) {
-            if (phase == PH_NODE) {
-                if ((g_bits & 0xffu) == 0u) { sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y; }
-                const int bit = 31 - __clz((int)(g_bits & 0xffu));
-                g_bits ^= 1u << bit;
-                const uint32_t child = (uint32_t)bit ^ octinv;
-                const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
-                if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
-                uint4 q0, q1, q2, q3, q4, q5, q6;
-                if ((int)ni < n_top) {
-                    // explicit address spaces: left generic, the two branches are merged into ONE flat_load through a selected pointer
-                    const LdsU4* q = top_lds + 8 * ni;
-                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
-                    if (STATS) cn.top_visits++;
-                } else {
-                    const GlobalU4* q = wnodes_g + 8 * (size_t)ni;
-                    q0 = u4(q[0]); q1 = u4(q[1]); q2 = u4(q[2]); q3 = u4(q[3]); q4 = u4(q[4]); q5 = u4(q[5]); q6 = u4(q[6]);
-                }
-                if (STATS) cn.node_visits++;
-                const WideStep st = wide_node_test(q0, q1, q2, q3, q4, q5, q6, p.o, inv, octinv, t_min, closest_t);
-                g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
-                t_base = st.tri_base; t_mask = st.tris;
-                if (t_mask) phase = PH_PRIM;
-                else if ((g_bits & 0xffu) == 0u && sp == 0) phase = after_walk();
-            }
-        } else if (c_prim >= c_shade) {
-            if (phase == PH_PRIM) {
-                const int k = (int)t_base + __ffs((int)t_mask) - 1;
-                t_mask &= t_mask - 1u;
-                if (STATS) cn.prim_tests++;
-                const f3p* r = reinterpret_cast<const f3p*>(a.sc.wprims) + 3 * (size_t)k;
-                const f3p v0 = r[0], e1 = r[1], e2 = r[2];
-                float tt = 0.0f;
-                const bool ok = mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), p.o, p.d, 1e-8f, t_lo, tt);
-                if (ok) {
-                    if (tt < closest_t) { closest_t = tt; slot_hit = k; }
-                    else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
-                        if (CERT) need_exact = true;                       // a tie: let the reference's walk decide
-                        else if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
-                    }
-                }
-                if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : after_walk();
-            }
-        } else {
             if (phase == PH_SHADE) {
                 const bool more = shade_step<STATS, GUIDED, true, BATCH>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn, slot);
                 segs_left--;

@@ -177,7 +177,8 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
 //     off by - t0' = fl(fl(lo - o) fl(1 / d)) lies within 3 * 2^-24 |lo - o| / |d| of the plane's true distance, Q_a' within
 //     4 * 2^-24 (|o_a| + big) of Q_a - so every entry distance comes out <= t <= max_dist and every exit distance >= t >= 1e-5.
 //     Needs |d_a| > 1e-8 (below that the reference replaces 1 / d by 1e8); otherwise, or within eps of a face: the exact
-//     anyhit_box over the leaf's ancestor list (wanc); a box of that list failing: the reference's own walk for this ray.
+//     anyhit_box over the leaf's ancestor list (wanc), leaf first, up to the first box that holds Q with the margin; a box of
+//     that list failing: the reference's own walk for this ray.
 template <bool CERT>
 __device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 lo, float4 hi, float t, f3 o, f3 d, float max_dist, int slot_a, int slot_b, unsigned int& chain) {
     const f3 q = o + t * d;
@@ -190,14 +191,18 @@ __device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 
     const f3 inv = mk3(1.0f / (fabsf(d.x) > 1e-8f ? d.x : 1e-8f), 1.0f / (fabsf(d.y) > 1e-8f ? d.y : 1e-8f), 1.0f / (fabsf(d.z) > 1e-8f ? d.z : 1e-8f));
     const uint32_t ref = __float_as_uint(lo.w);
     uint32_t off = ref >> 5;
-    bool ok = true;
-    for (int left = (int)(ref & 31u); left > 0 && ok; left--, off++) {
+    // leaf first: a box that holds Q with the margin settles every box above it; the ones below it have to pass the slab test
+    bool ok = true, proven = false;
+    for (int left = (int)(ref & 31u); left > 0 && ok && !proven; left--, off++) {
         const uint4 idx = sc.wanc[off];
         const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];          // padding repeats the root
-            ok = ok && anyhit_box(sc.nodes[2 * (size_t)j], sc.nodes[2 * (size_t)j + 1], o, inv, max_dist);
+            const float4 n0 = sc.nodes[2 * (size_t)j], n1 = sc.nodes[2 * (size_t)j + 1];
+            const bool holds = slopes && q.x - n0.x >= ex && n1.x - q.x >= ex && q.y - n0.y >= ey && n1.y - q.y >= ey && q.z - n0.z >= ez && n1.z - q.z >= ez;
+            ok = ok && (proven || holds || anyhit_box(n0, n1, o, inv, max_dist));
+            proven = proven || holds;
         }
     }
     if (ok && sc.w_cert_debug < 2) return true;

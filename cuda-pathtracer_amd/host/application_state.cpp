@@ -371,7 +371,7 @@ void SceneState::buildFast() {
     d_wmtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_wmtab");
     d_wload_index = (int*)upload_vec(h_wide.tri_load_index.data(), (size_t)n * sizeof(int), "d_wload_index");
     d_wref_slot = (int*)upload_vec(ref_slot.data(), (size_t)n * sizeof(int), "d_wref_slot");
-    // TRAVERSAL_CERTIFIED: per reference leaf the pre-order indices of its ancestors (root first, the leaf itself last) in chunks
+    // TRAVERSAL_CERTIFIED: per reference leaf the pre-order indices of its ancestors (the leaf itself first, the root last) in chunks
     // of four, padded with 0xffffffff; per fast-order triangle where its leaf's list starts and how many chunks it has; and the
     // way back from a reference leaf-order slot to the fast order (for the rays that take the reference's walk)
     {
@@ -388,7 +388,7 @@ void SceneState::buildFast() {
             for (int x = i; x >= 0; x = parent[x]) path.push_back(x);
             const size_t first_chunk = anc.size() / 4, chunks = (path.size() + 3) / 4;
             if (chunks > 31 || first_chunk >= (1u << 27)) { fits = false; break; }
-            for (size_t k = path.size(); k-- > 0;) anc.push_back((uint32_t)path[k]);
+            for (size_t k = 0; k < path.size(); k++) anc.push_back((uint32_t)path[k]);      // the leaf first, the root last
             while (anc.size() % 4) anc.push_back(0xffffffffu);
             leaf_ref[i] = (uint32_t)(first_chunk << 5) | (uint32_t)chunks;
         }
