@@ -122,11 +122,15 @@ CONFIGS = {
                          served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree without the certificate"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
-    "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
-                     served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp"),
+    "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide",
+                     served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp (default = certified walk: the reference's frame)"),
+    "c5strong_packed": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased", traversal=4,
+                            served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp through the reference's own tree (packed layout)"),
     "c5strong_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
                           served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp through the opt-in fast tree"),
-    "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_phased",
+    "c2_cert": dict(scene="cbox.obj", width=1024, height=1024, spp=256, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", traversal=6,
+                    served_from="lds/l1", what="BASELINE configs[1] with the certified walk forced (the automatic choice for 32 triangles is the sweep)"),
+    "c5": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_wide",
                served_from="l2/mall/hbm", what="BASELINE configs[4]"),
 }
 
@@ -388,7 +392,7 @@ def main():
 
     name = args.config
     cfg = dict(CONFIGS[name])
-    strong = name in ("c4", "c5", "c5strong", "c5strong_fast")
+    strong = name in ("c4", "c5", "c5strong", "c5strong_packed", "c5strong_fast")
     if name == "c2" and world > 1:                    # weak scaling of the headline configuration
         cfg["width"] = cfg["height"] = int(round(1024 * math.sqrt(n_gpus)))
     if args.side:
@@ -560,12 +564,12 @@ def main():
 
     # N > 1, default line: `value` stays the weak-scaled headline configuration; BASELINE's own multi-GPU configurations are
     # timed in the same run as STRONG scaling (fixed frame, rows tiled over the N ranks, one RCCL gather per frame): configs[3]
-    # (c4, at its full 512 spp) and configs[4] (c5, the 1 M-triangle frame at 64 of its 2048 spp, through the reference's tree
-    # and through the opt-in fast tree).  A failure here is recorded in the line and does not cost the headline number.
+    # (c4, at its full 512 spp) and configs[4] (c5, the 1 M-triangle frame at 64 of its 2048 spp: the default = certified walk,
+    # the reference's own tree, and the opt-in fast tree without the certificate).  A failure here is recorded in the line and does not cost the headline number.
     if world > 1 and name == "c2" and not args.no_extra and not args.side and not args.spp:
         extras = []
         loaded = cfg["scene"]
-        for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_fast", 3)):
+        for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_packed", 3), ("c5strong_fast", 3)):
             try:
                 xcfg = dict(CONFIGS[xname])
                 if args.rehearse_gloo or args.rehearse_shared_gpu:     # rehearsal on one shared GPU: same control flow, small frames

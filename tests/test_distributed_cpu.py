@@ -217,7 +217,7 @@ def test_bench_line_carries_every_contract_field():
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 3` with NO launcher around it (WORLD_SIZE unset), as the driver may run it: bench.py starts the three
     ranks itself before anything touches a GPU, relays rank 0's line and exits with the worst child's code.  Default N > 1 line:
-    weak-scaled c2 as `value` plus the strong-scaled BASELINE configurations (c4, c5 through both trees; shrunk here by the
+    weak-scaled c2 as `value` plus the strong-scaled BASELINE configurations (c4; c5 by the default walk and through both trees; shrunk here by the
     rehearsal switch) and the rank count RCCL itself reports.  The ranks share the test box's GPU over tests/mock_rccl.cpp."""
     import json
     root = os.path.dirname(HERE)
@@ -231,7 +231,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["scaling"] == "weak" and line["value"] > 0 and line["rccl_ranks"] == 3
     extras = {e["name"]: e for e in line["extra_configs"]}
-    assert set(extras) == {"c4", "c5strong", "c5strong_fast"} and all("error" not in e and e["value"] > 0 and e["scaling"] == "strong" for e in extras.values()), extras
+    assert set(extras) == {"c4", "c5strong", "c5strong_packed", "c5strong_fast"} and all("error" not in e and e["value"] > 0 and e["scaling"] == "strong" for e in extras.values()), extras
     # a rank that fails must fail the whole run: an unknown flag makes every child exit non-zero
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
