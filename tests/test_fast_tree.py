@@ -318,6 +318,50 @@ def test_certified_walk_is_exact_and_the_default_of_large_triangle_scenes(R):
 
 
 @pytest.mark.gpu
+def test_certified_walk_under_guided_sampling_frame_batches_and_tiles(R):
+    """Everything above the hit query on a scene where the certified walk is the automatic choice (36 864 triangles): the grid /
+    MIS sampling branches (GUIDED build of ptmi_bounce_wide<..., CERT>; records reached through the walk's own load-order
+    table), a pipelined batch of frames (BATCH build) and a rank's interleaved rows of a tiled frame - each against the oracle."""
+    arrs = tess(48, 24)
+    R.load_scene_arrays(*arrs)
+    assert R.set_traversal(-1) == R.CERTIFIED
+    o = OracleScene.from_arrays(*arrs)
+    W, H, spp, depth = 96, 64, 5, 6
+    rng = np.random.default_rng(77)
+    grids = (rng.random((o.n_prims, 256, 3)) ** 3).astype(F)
+    grids[rng.random(o.n_prims) < 0.2] = 0.0
+    try:
+        R.set_radiosity_grids(grids); o.set_radiosity_grids(grids); o.set_mis_fraction(0.4)
+        for mode in (1, 3):
+            R.update_resolution(W, H)
+            R.set_config(spp=spp, max_depth=depth, sampling_mode=mode, mis_bsdf_fraction=0.4, collect_stats=False)
+            R.render_frame()
+            rgb, rad = R.read_image()
+            orgb, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, sampling_mode=mode)
+            assert (bits(rad) == bits(orad)).all() and (rgb == orgb).all(), f"guided mode {mode}"
+        R.set_config(sampling_mode=0, mis_bsdf_fraction=0.5); R.set_radiosity_grids(None); o.set_radiosity_grids(None)
+        # three frames as one pipelined batch
+        state = np.zeros((H * W, 6), np.uint32)
+        want = []
+        for k in range(3):
+            _, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, rng_state=state, reset_rng=(k == 0))
+            want.append(orad.copy())
+        R.update_resolution(W, H)
+        R.render_frames(3)
+        for k in (2, 0, 1):
+            R.select_frame(k)
+            assert (bits(R.read_image(rgb8=False)[1]) == bits(want[k])).all(), f"batch frame {k}"
+        # rank 1 of 3, interleaved 4-row blocks
+        R.update_resolution(W, H, n_ranks=3, rank=1, row_block=4)
+        R.render_frame()
+        rows = R.local_rows()
+        assert (bits(R.read_image(rgb8=False)[1]) == bits(want[0].reshape(H, W, 3)[rows])).all()
+    finally:
+        R.set_config(sampling_mode=0, mis_bsdf_fraction=0.5, collect_stats=False); R.set_radiosity_grids(None)
+        R.update_resolution(W, H)
+
+
+@pytest.mark.gpu
 def test_certified_walk_sends_what_it_cannot_prove_through_the_references_walk(R):
     """The three ways out of the proof, each forced: (1) EVERY hit a tie - the scene holds every triangle twice, with another
     colour, so the reference's "first visited wins" decides every pixel; (2) ray origins outside the range the boxes are padded
