@@ -307,7 +307,7 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     fast = bool(cfg.get("fast"))
     r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False, fast_tree=False)
     auto = r.set_traversal(-1)
-    own_walk = fast or (auto == r.CERTIFIED and not cfg.get("traversal"))
+    own_walk = fast or (auto == r.CERTIFIED and cfg.get("traversal") is None)
     if auto == r.CERTIFIED:
         r.set_traversal(r.PACKED)
     st_counts = r.render_frame()

@@ -885,10 +885,12 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     if (active) load_path(a.st, a.tm, slot, p);
     LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
 
-    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3, PH_VERIFY = 4 };
+    enum { PH_NODE = 0, PH_PRIM = 1, PH_SHADE = 2, PH_DONE = 3, PH_VERIFY = 4, PH_EXACT = 5 };
+    constexpr int kTieFlag = 0x40000000;      // CERT: set in slot_hit while a second triangle is accepted at exactly closest_t
     const float t_min = 1e-4f, t_lo = mt_t_lo(t_min);
-    bool need_exact = false;                  // CERT: this ray goes through the reference's own walk
-    uint32_t v_off = 0u; int v_left = 0;      // CERT: next 4-node chunk of the hit leaf's ancestor list, chunks left
+    // CERT keeps no state of its own through the walk: a tie is a flag in slot_hit (a closer hit clears it - only a tie at the
+    // final t* matters), a ray that has to take the reference's walk is a phase (PH_EXACT), and the proof's cursor (next 4-node
+    // chunk of the hit leaf's ancestor list, chunks left) lives in g_base / t_base, which are dead once the walk has ended
     int phase = alive ? PH_NODE : PH_DONE;
     int segs_left = a.segments;
     int slot_hit = -1, sp = 0;
@@ -901,12 +903,13 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     // where the walk goes when it has run out of nodes and triangles
     auto after_walk = [&]() -> int {
         if (!CERT) return PH_SHADE;
-        if (!need_exact && slot_hit < 0) return PH_SHADE;
-        v_left = -1;                                                   // first the one-fetch certificate, then (rarely) the chain
+        if (slot_hit < 0) return PH_SHADE;
+        if (slot_hit & kTieFlag) return PH_EXACT;                      // a tie at t*: let the reference's walk decide
+        t_base = 0xffffffffu;                                          // first the one-fetch certificate, then (rarely) the chain
         return PH_VERIFY;
     };
     auto origin_in_range = [&]() { return fmaxf(fabsf(p.o.x), fmaxf(fabsf(p.o.y), fabsf(p.o.z))) <= a.sc.w_guard; };
-    if (CERT && alive && !origin_in_range()) { need_exact = true; g_bits = 1u << 8; phase = after_walk(); }
+    if (CERT && alive && !origin_in_range()) phase = PH_EXACT;
 
     while (true) {
         const int c_node = __popcll(__ballot(phase == PH_NODE));
@@ -914,7 +917,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
         // a lane whose hit has to be proven (VERIFY) votes with the SHADE lanes and takes one proof step right before that
         // phase's work - for almost every hit the only one (the leaf-box fetch).  As a phase of its own (round 3's first form)
         // the proof cost a wave iteration per ray and its stragglers waited for a majority: c5tile 1 407 -> 1 455 Msamples/s
-        const int c_shade = __popcll(__ballot(phase == PH_SHADE || (CERT && phase == PH_VERIFY)));
+        const int c_shade = __popcll(__ballot(phase == PH_SHADE || (CERT && phase >= PH_VERIFY)));
         if (c_node + c_prim + c_shade == 0) break;
         if (c_node >= c_prim && c_node >= c_shade) {
             if (phase == PH_NODE) {
@@ -954,15 +957,15 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 if (ok) {
                     if (tt < closest_t) { closest_t = tt; slot_hit = k; }
                     else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
-                        if (CERT) need_exact = true;                       // a tie: let the reference's walk decide
+                        if (CERT) slot_hit |= kTieFlag;
                         else if (a.sc.wref_slot[k] < a.sc.wref_slot[slot_hit]) slot_hit = k;
                     }
                 }
                 if (t_mask == 0u) phase = ((g_bits & 0xffu) != 0u || sp > 0) ? PH_NODE : after_walk();
             }
         } else {
-            if (CERT && phase == PH_VERIFY) {
-                if (!need_exact && v_left < 0) {
+            if (CERT && phase >= PH_VERIFY) {
+                if (phase == PH_VERIFY && t_base == 0xffffffffu) {
                     // ONE fetch: the box of the hit triangle's leaf in the reference's tree.  Boxes are nested, so if the hit point
                     // Q = o + t* d lies inside the LEAF's box by eps on every face, it lies inside every ancestor's by at least
                     // as much - and eps = 2^-20 (|o_a| + big) is more than the reference's slab arithmetic can be off by on any box
@@ -981,13 +984,13 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     if (inside && finite_slopes) phase = PH_SHADE;
                     else {
                         const uint32_t ref = __float_as_uint(lo.w);
-                        v_off = ref >> 5; v_left = (int)(ref & 31u);
+                        g_base = ref >> 5; t_base = ref & 31u;
                         inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));       // the reference's 1 / d for its slab tests
                         if (STATS) cn.cert_chain++;
                     }
-                } else if (!need_exact) {
-                    const uint4 idx = a.sc.wanc[v_off];
-                    v_off++; v_left--;
+                } else if (phase == PH_VERIFY) {
+                    const uint4 idx = a.sc.wanc[g_base];
+                    g_base++; t_base--;
                     const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
                     float4 n0[4], n1[4];
 #pragma unroll
@@ -1013,16 +1016,16 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                         proven = proven || holds;
                     }
                     if (STATS) cn.node_visits += 4;
-                    if (failed) need_exact = true;
-                    else if (proven || v_left == 0) phase = PH_SHADE;
+                    if (failed) phase = PH_EXACT;
+                    else if (proven || t_base == 0u) phase = PH_SHADE;
                 }
-                if (need_exact) {                                      // the reference's walk itself, for this ray only
+                if (phase == PH_EXACT) {                               // the reference's walk itself, for this ray only
                     float t_ref = 0.0f; int slot_ref = -1;
                     const bool h = intersect_lane<false, STATS>(a.sc.nodes, a.sc.prims, a.sc.prim_stride, a.sc.n_nodes, true, p.o, p.d, t_min, FLT_MAX,
                                                                 t_ref, slot_ref, cn);
                     closest_t = h ? t_ref : FLT_MAX;
                     slot_hit = h ? a.sc.wfast_of_ref[slot_ref] : -1;
-                    need_exact = false; phase = PH_SHADE;
+                    phase = PH_SHADE;
                     if (STATS) cn.cert_fallback++;
                 }
             }
@@ -1038,7 +1041,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     g_base = 0u; g_bits = (1u << 8) | (1u << octinv);
                     phase = PH_NODE;
                     if (STATS) cn.rays++;
-                    if (CERT && !origin_in_range()) { need_exact = true; g_bits = 1u << 8; phase = after_walk(); }
+                    if (CERT && !origin_in_range()) phase = PH_EXACT;
                 }
             }
         }
