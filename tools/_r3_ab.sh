@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
-timeout -k 10 300 python tools/_r3_exh.py
-for c in c2 c2_sweep c3 c3_sweep; do timeout -k 10 300 python bench.py --config $c --steps 6 --warmup 2 --no-cpu --no-extra > gpurun_out/r3_exh_$c.json; python - <<PY
-import json; d=json.loads(open("gpurun_out/r3_exh_$c.json").read().strip().splitlines()[-1]); print("$c", d["value"], d["ms_per_step"], d["roofline"]["kernel"], {k:v for k,v in d["config"].items() if "walk" in k or "cert" in k})
-PY
-done
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q --timeout=600 > gpurun_out/r3_tests_full_5.log 2>&1 || { tail -40 gpurun_out/r3_tests_full_5.log; exit 1; }
+tail -3 gpurun_out/r3_tests_full_5.log
+timeout -k 10 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench_final2.json 2> gpurun_out/r3_bench_final2.err || { tail -20 gpurun_out/r3_bench_final2.err; exit 1; }
+python tools/design_table.py gpurun_out/r3_bench_final2.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
