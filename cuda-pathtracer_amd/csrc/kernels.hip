@@ -859,7 +859,10 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // again by the reference's own walk (intersect_lane) inside this kernel: about one ray in 10^9.  No hit at all needs no
 // check: the reference can only accept triangles the fast walk would have found.
 // pending triangles tested per PRIM step (records fetched together): 1 / 2 / 3: c5tile 1 555 / 1 646 / 1 586, c5frame 2 248 / 2 339 / 2 277
-// Msamples/s (certified walk; 3 spills 9 registers)
+// Msamples/s (certified walk; 3 spills 9 registers).  Measured and dropped in the same spirit (one dependent fetch less per
+// step): the material record fetched together with the certificate's leaf box (+0.5 %: noise); the first dword of the node a
+// lane will fetch after its triangles requested at the NODE -> PRIM transition, so that the line arrives during the PRIM step
+// (-8 %: loads return in order, the PRIM step then waits for the node's miss as well)
 #ifndef PTMI_PRIM_BATCH
 #define PTMI_PRIM_BATCH 2
 #endif
