@@ -577,6 +577,13 @@ int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, i
     });
 }
 
+int ptmi_debug_get_traversal(const ptmi_ctx* c, int* out_mode) {
+    return guarded([&] {
+        need(c != nullptr && out_mode != nullptr, "ctx / out_mode is NULL");
+        *out_mode = c->app.scene.d_nodes ? c->app.scene.d_scene.traversal : -1;
+    });
+}
+
 int ptmi_debug_set_solver_walk(ptmi_ctx* c, int force_walk, int min_prims) {
     return guarded([&] {
         need(c != nullptr, "ctx is NULL");

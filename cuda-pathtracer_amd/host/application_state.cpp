@@ -200,10 +200,10 @@ void SceneState::upload() {
     const size_t scene_bytes = (nodes.size() + prims.size() + mats.size()) * sizeof(float4);
     d_scene.lds_resident = (scene_bytes + (size_t)d_scene.stack_entries * kBlock * sizeof(int)) <= 64 * 1024 ? 1 : 0;
     buildPacked();
-    // Large triangle scenes (the ones the packed layout is built for): the 8-wide tree + the certificate data of
-    // TRAVERSAL_CERTIFIED - the default walk there: the reference's hit for every ray, by proof or by its own walk, at about
-    // twice the exact walk's rate (1 M triangles: +1.3 s of loading, +145 MB)
-    if (d_gnodes && !num_quads && bvh_depth <= 62 && certified_default) buildFast();
+    // Triangle scenes beyond the sweep's few dozen primitives: the 8-wide tree + the certificate data of TRAVERSAL_CERTIFIED - the
+    // default walk there: the reference's hit for every ray, by proof or by its own walk, at 1.4 - 2.3 x the rate of the walk over
+    // the reference's tree (128 ... 1 M triangles, planar scenes included; 1 M triangles: +1.3 s of loading, +145 MB)
+    if (n > sweep_max_prims && !num_quads && bvh_depth <= 62 && certified_default) buildFast();
     chooseTraversal();
 }
 
@@ -649,7 +649,7 @@ void SceneState::chooseTraversal() {
     if (!d_nodes) return;
     if (bvh_depth > 62) d_scene.traversal = TRAVERSAL_STACK;           // the reference's stack-overflow rule can trigger
     else if ((int)h_primitives.size() <= sweep_max_prims) d_scene.traversal = TRAVERSAL_SWEEP;
-    else d_scene.traversal = d_scene.gnodes ? (certified_default && d_scene.wnodes && d_scene.wcert ? TRAVERSAL_CERTIFIED : TRAVERSAL_PACKED) : TRAVERSAL_PHASED;
+    else d_scene.traversal = certified_default && d_scene.wnodes && d_scene.wcert && d_scene.wanc ? TRAVERSAL_CERTIFIED : (d_scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED);
     // PHASED: measured faster than the segment-synchronous LANE walk from 128 primitives up (LDS-resident or not); PACKED: the
     // phased walk over the packed layout of scenes too large for LDS; LANE stays available through the override
     if (force_traversal >= 0 && !(force_traversal != TRAVERSAL_STACK && bvh_depth > 62)) d_scene.traversal = force_traversal;

@@ -29,7 +29,7 @@ EXPORTS = [
     "ptmi_dist_unique_id", "ptmi_dist_init", "ptmi_dist_finalize", "ptmi_gather_frame", "ptmi_gather_wait", "ptmi_frame_device",
     "ptmi_read_frame", "ptmi_dist_barrier", "ptmi_dist_allreduce_max", "ptmi_debug_place_tiles", "ptmi_debug_set_packed_min_nodes", "ptmi_debug_set_packed_top", "ptmi_render_frames", "ptmi_select_frame",
     "ptmi_debug_set_fast_tree", "ptmi_debug_intersect_fast", "ptmi_dist_comm_count", "ptmi_host_fast_tree_build", "ptmi_host_fast_tree_intersect", "ptmi_host_fast_tree_stats",
-    "ptmi_debug_set_solver_walk",
+    "ptmi_debug_set_solver_walk", "ptmi_debug_get_traversal",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
         L.ptmi_debug_cosine_sample.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.ptmi_debug_set_traversal.argtypes = [vp, C.c_int, C.c_int, ip]
         L.ptmi_debug_set_solver_walk.argtypes = [vp, C.c_int, C.c_int]
+        L.ptmi_debug_get_traversal.argtypes = [vp, ip]
         L.ptmi_debug_rcp_check.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.ptmi_host_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.ptmi_host_scene_from_arrays.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.POINTER(vp)]
@@ -512,6 +513,12 @@ class Renderer:
         """Returns the traversal mode in effect for the loaded scene (-1 if none)."""
         m = C.c_int(-1)
         self._ck(self.L.ptmi_debug_set_traversal(self.h, int(force_mode), int(sweep_max_prims), C.byref(m)))
+        return m.value
+
+    def traversal(self):
+        """The traversal mode in effect for the loaded scene (-1 if none); changes nothing."""
+        m = C.c_int(-1)
+        self._ck(self.L.ptmi_debug_get_traversal(self.h, C.byref(m)))
         return m.value
 
     def set_solver_walk(self, force_walk=-1, min_prims=256):

@@ -324,6 +324,8 @@ int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int ro
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
 int ptmi_debug_set_traversal(ptmi_ctx*, int force_mode, int sweep_max_prims, int* out_mode);
+/* The mode in effect for the loaded scene (-1 without one), nothing changed. */
+int ptmi_debug_get_traversal(const ptmi_ctx*, int* out_mode);
 /* The visibility walk of the radiosity pre-pass's form-factor kernel: force_walk -1 = automatic (certified from min_prims
  * triangles up, default 256; else the reference's), 0 = the reference's own tree, 2 = certified (the fast tree + a per-ray
  * proof that the reference's any-hit walk answers the same; triangle scenes no deeper than 30; test hooks: 3 / 4 = certified
