@@ -88,15 +88,17 @@ typedef struct {
     int      download_image;      /* 1: ptmi_render_frame ends like renderFrame() does, with the D2H of the 8-bit image into the
                                    * ctx's pinned host image (RenderState::h_image, application.h:211) - read it through
                                    * ptmi_host_image.  0 (default): results stay on the device until asked for */
-    int      fast_tree;           /* 0 (default): walk the reference's own tree (rendering/bvh.h:156-218) - frames bit-identical
-                                   * to the reference's.  1: opt-in FAST tree for triangle scenes (last bullet): an
-                                   * 8-wide binned-SAH tree with conservatively quantised boxes, built at the first frame that
-                                   * asks for it.  Triangles, hit arithmetic, RNG draws and shading are untouched; a ray's hit can
-                                   * differ only where two triangles are hit at exactly the same t or where the reference's own
-                                   * slab test drops a grazing box (cuda-pathtracer_amd/csrc/wide_bvh.h).  Scenes with quads
-                                   * keep the exact walk.  ptmi_run_radiosity_solver reads the switch too: its visibility walk
-                                   * (form_factors.h:143-208) then goes through the same tree (n = 8192: 132 -> 70 ms; 2 of
-                                   * 67 M form factors differ, the whole solution at n = 2048 is bit-identical) */
+    int      fast_tree;           /* 0 (default): every ray's hit is the one the reference's walk over its own tree
+                                   * (rendering/bvh.h:156-218) returns - frames bit-identical to the reference's.  (Triangle scenes
+                                   * above 64 primitives get there through an 8-wide binned-SAH tree plus a per-ray proof, else the
+                                   * reference's walk for that ray: the certified walk)  1: opt-in, the same tree
+                                   * WITHOUT the proof (last bullet; about 7 % faster): triangles, hit arithmetic, RNG
+                                   * draws and shading are untouched; a ray's hit can differ only where two triangles are hit at
+                                   * exactly the same t or where the reference's own slab test drops a grazing box
+                                   * (cuda-pathtracer_amd/csrc/wide_bvh.h: 1 pixel of 4 M on a 1 M-triangle frame).  Scenes with
+                                   * quads keep the reference's tree.  ptmi_run_radiosity_solver reads the switch too: its
+                                   * visibility walk (form_factors.h:143-208) then skips the proof as well (n = 8192: 84 -> 71 ms;
+                                   * 2 of 67 M form factors differ) */
 } ptmi_config;
 
 /* Framebuffer sharding (new in this implementation; the reference is single-GPU).
@@ -319,7 +321,8 @@ int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int ro
  * 0 = wave-uniform sweep, 1 = per-lane stackless, 2 = explicit stack, 3 = per-lane with wave-scheduled phases,
  * 4 = 3 over the packed layout (sibling-pair node order, 36-byte triangles; only where that layout was built, else 3);
  * 6 = certified: the 8-wide tree of ptmi_config.fast_tree + a per-ray proof that the reference's walk returns the same hit,
- *     else the reference's walk for that ray (triangle scenes; results identical, the node / test counters are its own);
+ *     else the reference's walk for that ray (results identical, the node / test counters are its own) - the automatic choice
+ *     of every triangle scene above sweep_max_prims whose tree is no deeper than 62;
  * sweep_max_prims = largest scene (primitives)
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
