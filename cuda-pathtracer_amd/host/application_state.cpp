@@ -203,7 +203,10 @@ void SceneState::upload() {
     // Triangle scenes beyond the sweep's few dozen primitives: the 8-wide tree + the certificate data of TRAVERSAL_CERTIFIED - the
     // default walk there: the reference's hit for every ray, by proof or by its own walk, at 1.4 - 2.3 x the rate of the walk over
     // the reference's tree (128 ... 1 M triangles, planar scenes included; 1 M triangles: +1.3 s of loading, +145 MB)
-    if (n > sweep_max_prims && !num_quads && bvh_depth <= 62 && certified_default) buildFast();
+    if (n > sweep_max_prims && !num_quads && bvh_depth <= 62 && certified_default) {
+        try { buildFast(); }
+        catch (const ArgError&) { freeFast(); }        // a scene the builder declines (tree deeper than 48): the reference's tree is walked
+    }
     chooseTraversal();
 }
 
