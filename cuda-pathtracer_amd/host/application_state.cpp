@@ -835,7 +835,8 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // long as the chain of its heaviest pixels, every launch boundary makes it wait for the slowest wave once more, and the
     // rest of the frame goes into ONE launch per chunk (1 M-triangle scene, 1/8 of the frame: 47 instead of 59 ms; with more
     // waves than slots one launch is slower, the second round starts a whole chain late) - DESIGN.md 5
-    const int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
+    // (the phased kernels: spp / 4, see below)
+    int segments = g.config.segments_per_launch > 0 ? g.config.segments_per_launch : 32;
     // "the rest of the frame": bounded so that one launch stays well below a minute (a lane of the 1 M-triangle scene does
     // ~4 000 segments per second; BASELINE's 2048 spp x 8 bounces = 16 384 segments at most = ONE 1.45 s launch per chunk.  A
     // boundary in mid-frame is dear: with 8 192 the same frame took 1.58 s)
@@ -851,6 +852,15 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     if (scene.traversal == TRAVERSAL_CERTIFIED && !(g.scene.fastReady() && scene.wanc)) scene.traversal = scene.gnodes ? TRAVERSAL_PACKED : TRAVERSAL_PHASED;
     const int trav = scene.traversal;
     const bool phased = trav == TRAVERSAL_PHASED || trav == TRAVERSAL_PACKED || trav == TRAVERSAL_WIDE || trav == TRAVERSAL_CERTIFIED;
+    // The phased kernels keep their lanes busy across sample boundaries, so a launch boundary buys them only the compaction; with
+    // many samples per pixel fewer, longer launches win: spp / 4 segments, at least 32, at most 512 (1 M-triangle scene, certified
+    // walk, Msamples/s with 32 / 128 / 512 segments: an eighth of the frame at 2048 spp 1 787 / 1 895 / 1 943, at 256 spp 1 706 /
+    // 1 801 / -; the whole frame at 512 spp 2 444 / 2 531 / 2 514 (256), at 64 spp 2 341 / 2 267 / -)
+    if (phased && g.config.segments_per_launch <= 0) segments = std::min(512, std::max(32, g.config.spp / 4));
+    // "the rest of the frame" for the 8-wide walks: at most 512 segments, then compaction - what a 64-spp frame has left at that
+    // point anyway; with BASELINE's 2048 spp the pixels of a tile finish far apart, and re-packing the living ones every 512
+    // segments beats one launch to the end (an eighth of the 1 M-triangle frame, 2048 spp: 1 943 against 1 824 Msamples/s)
+    const int rest_segments = trav == TRAVERSAL_WIDE || trav == TRAVERSAL_CERTIFIED ? std::max(segments, 512) : kRestOfFrameSegments;
     const long long fit_pct = phased ? 120 : 30;
     const long long wave_slots = g.config.segments_per_launch > 0 || !(phased || trav == TRAVERSAL_SWEEP)
                                      ? 0 : bounce_resident_waves(scene, fp, g.config.collect_stats, g.n_cus);
@@ -941,7 +951,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * fit_pct;
                 launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
                               u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
-                              fits ? kRestOfFrameSegments : segments, want_stats ? r.d_stats : nullptr,
+                              fits ? rest_segments : segments, want_stats ? r.d_stats : nullptr,
                               phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream, pub);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
