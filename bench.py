@@ -565,11 +565,11 @@ def main():
     # N > 1, default line: `value` stays the weak-scaled headline configuration; BASELINE's own multi-GPU configurations are
     # timed in the same run as STRONG scaling (fixed frame, rows tiled over the N ranks, one RCCL gather per frame): configs[3]
     # (c4, at its full 512 spp) and configs[4] (c5, the 1 M-triangle frame at 64 of its 2048 spp: the default = certified walk,
-    # the reference's own tree, and the opt-in fast tree without the certificate).  A failure here is recorded in the line and does not cost the headline number.
+    # the reference's own tree, and the opt-in fast tree without the certificate; and ONE frame at the full 2048 spp, default walk).  A failure here is recorded in the line and does not cost the headline number.
     if world > 1 and name == "c2" and not args.no_extra and not args.side and not args.spp:
         extras = []
         loaded = cfg["scene"]
-        for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_packed", 3), ("c5strong_fast", 3)):
+        for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_packed", 3), ("c5strong_fast", 3), ("c5", 1)):
             try:
                 xcfg = dict(CONFIGS[xname])
                 if args.rehearse_gloo or args.rehearse_shared_gpu:     # rehearsal on one shared GPU: same control flow, small frames

@@ -231,7 +231,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["scaling"] == "weak" and line["value"] > 0 and line["rccl_ranks"] == 3
     extras = {e["name"]: e for e in line["extra_configs"]}
-    assert set(extras) == {"c4", "c5strong", "c5strong_packed", "c5strong_fast"} and all("error" not in e and e["value"] > 0 and e["scaling"] == "strong" for e in extras.values()), extras
+    assert set(extras) == {"c4", "c5strong", "c5strong_packed", "c5strong_fast", "c5"} and all("error" not in e and e["value"] > 0 and e["scaling"] == "strong" for e in extras.values()), extras
     # a rank that fails must fail the whole run: an unknown flag makes every child exit non-zero
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
