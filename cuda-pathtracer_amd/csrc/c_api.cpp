@@ -568,7 +568,7 @@ int ptmi_debug_set_traversal(ptmi_ctx* c, int force_mode, int sweep_max_prims, i
         need(sweep_max_prims >= 0, "sweep_max_prims must be >= 0");
         SceneState& s = c->app.scene;
         s.force_traversal = force_mode; s.sweep_max_prims = sweep_max_prims;
-        if (force_mode == TRAVERSAL_CERTIFIED && s.d_nodes && !s.num_quads && !s.fastReady()) {
+        if (force_mode == TRAVERSAL_CERTIFIED && s.d_nodes && !s.fastReady()) {
             PTMI_HIP(hipSetDevice(c->app.device_id));
             s.buildFast();
         }
@@ -627,7 +627,7 @@ int ptmi_debug_set_fast_tree(ptmi_ctx* c, int max_leaf, float c_trav, float c_tr
         PTMI_HIP(hipSetDevice(c->app.device_id));
         SceneState& s = c->app.scene;
         s.wide_params.max_leaf = max_leaf; s.wide_params.c_trav = c_trav; s.wide_params.c_tri = c_tri; s.wide_top_nodes = top_nodes;
-        if (s.d_nodes && !s.num_quads) s.buildFast();
+        if (s.d_nodes) s.buildFast();
         if (n_nodes) *n_nodes = s.d_scene.w_nodes;
         if (depth) *depth = s.h_wide.depth;
         if (n_top) *n_top = s.d_scene.w_top;

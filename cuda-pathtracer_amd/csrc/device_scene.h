@@ -70,6 +70,7 @@ struct DeviceScene {
     const int* wref_slot = nullptr;    // fast order -> reference leaf-order slot (equal-t hits keep the smaller one, scene.h:89-90)
     // TRAVERSAL_CERTIFIED: what the VERIFY phase and the fallback read (kernels.hip: bounce_wide_body, CERT)
     const uint4* wanc = nullptr;       // per reference leaf: its ancestors' pre-order node indices (leaf included), 4 per chunk, 0xffffffff pads
+    const float4* wqprims = nullptr;   // scenes with quads: 64-byte records (v0 | type, e1, e2, e3) in the fast tree's order instead of wprims
     const float4* wcert = nullptr;     // per fast-order triangle: (leaf box min, bits(first chunk << 5 | chunks of the leaf's list)) (leaf box max, 0)
     float w_big = 0.0f;                // the scene's largest |coordinate|
     int w_cert_debug = 0;              // test hook of the solver's certified walk: 1 every blocked ray takes the ancestor chain, 2 the reference's walk

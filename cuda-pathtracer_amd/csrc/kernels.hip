@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 #ifndef PTMI_PRIM_BATCH
 #define PTMI_PRIM_BATCH 2
 #endif
-template <bool STATS, bool GUIDED, bool BATCH, bool CERT>
+template <bool STATS, bool GUIDED, bool BATCH, bool CERT, bool QUADS>
 __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
     const int n_in = a.count_in ? *a.count_in : a.n_in;
@@ -956,24 +956,43 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
             if (phase == PH_PRIM) {
                 // up to PTMI_PRIM_BATCH pending triangles per step: their records are fetched together (one latency), then tested
                 // in ascending order
-                int kk[PTMI_PRIM_BATCH]; bool has[PTMI_PRIM_BATCH]; f3p r0[PTMI_PRIM_BATCH], r1[PTMI_PRIM_BATCH], r2[PTMI_PRIM_BATCH];
+                // (scenes with quads: one 64-byte record per step - v0 | type, e1, e2, e3, the layout of d_prims)
+                constexpr int kPB = QUADS ? 1 : PTMI_PRIM_BATCH;
+                int kk[kPB]; bool has[kPB]; f3p r0[kPB], r1[kPB], r2[kPB]; float4 q0[kPB], q1[kPB], q2[kPB], q3[kPB];
 #pragma unroll
-                for (int b = 0; b < PTMI_PRIM_BATCH; b++) {
+                for (int b = 0; b < kPB; b++) {
                     has[b] = t_mask != 0u;
                     kk[b] = has[b] ? (int)t_base + __ffs((int)t_mask) - 1 : (b ? kk[b - 1] : 0);
                     t_mask &= t_mask - 1u;                                 // 0 stays 0
-                    const f3p* r = reinterpret_cast<const f3p*>(a.sc.wprims) + 3 * (size_t)kk[b];
-                    r0[b] = r[0]; r1[b] = r[1]; r2[b] = r[2];
+                    if (QUADS) {
+                        const float4* r = a.sc.wqprims + 4 * (size_t)kk[b];
+                        q0[b] = r[0]; q1[b] = r[1]; q2[b] = r[2]; q3[b] = r[3];
+                    } else {
+                        const f3p* r = reinterpret_cast<const f3p*>(a.sc.wprims) + 3 * (size_t)kk[b];
+                        r0[b] = r[0]; r1[b] = r[1]; r2[b] = r[2];
+                    }
                 }
 #pragma unroll
-                for (int b = 0; b < PTMI_PRIM_BATCH; b++) {
+                for (int b = 0; b < kPB; b++) {
                     if (b > 0 && !__any(has[b])) break;
                     if (has[b]) {
                         const int k = kk[b];
                         if (STATS) cn.prim_tests++;
-                        const f3 v0 = mk3(r0[b].x, r0[b].y, r0[b].z), e1 = mk3(r1[b].x, r1[b].y, r1[b].z), e2 = mk3(r2[b].x, r2[b].y, r2[b].z);
                         float tt = 0.0f;
-                        const bool ok = mt_hit(v0, e1, e2, p.o, p.d, 1e-8f, t_lo, tt);
+                        bool ok;
+                        if (QUADS && __float_as_int(q0[b].w) != 0) {
+                            // Quad::intersect under an upper bound returns the smaller t of its two halves whenever that is below
+                            // the bound (each half accepts t < closest, the second sees the first's result): quad.h:56-121
+                            const float eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+                            const float ta = mt_candidate(xyz(q0[b]), xyz(q1[b]), xyz(q2[b]), p.o, p.d, eps_up, t_lo);
+                            const float tb = mt_candidate(xyz(q0[b]), xyz(q2[b]), xyz(q3[b]), p.o, p.d, eps_up, t_lo);
+                            tt = min_raw(ta, tb);
+                            ok = tt < __builtin_inff();
+                        } else {
+                            const f3 v0 = QUADS ? xyz(q0[b]) : mk3(r0[b].x, r0[b].y, r0[b].z), e1 = QUADS ? xyz(q1[b]) : mk3(r1[b].x, r1[b].y, r1[b].z),
+                                     e2 = QUADS ? xyz(q2[b]) : mk3(r2[b].x, r2[b].y, r2[b].z);
+                            ok = mt_hit(v0, e1, e2, p.o, p.d, 1e-8f, t_lo, tt);
+                        }
                         if (ok) {
                             if (tt < closest_t) { closest_t = tt; slot_hit = k; }
                             else if (tt == closest_t && slot_hit >= 0) {           // the reference keeps the hit it visits first (scene.h:89-90)
@@ -1043,7 +1062,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 }
                 if (phase == PH_EXACT) {                               // the reference's walk itself, for this ray only
                     float t_ref = 0.0f; int slot_ref = -1;
-                    const bool h = intersect_lane<false, STATS>(a.sc.nodes, a.sc.prims, a.sc.prim_stride, a.sc.n_nodes, true, p.o, p.d, t_min, FLT_MAX,
+                    const bool h = intersect_lane<QUADS, STATS>(a.sc.nodes, a.sc.prims, a.sc.prim_stride, a.sc.n_nodes, true, p.o, p.d, t_min, FLT_MAX,
                                                                 t_ref, slot_ref, cn);
                     closest_t = h ? t_ref : FLT_MAX;
                     slot_hit = h ? a.sc.wfast_of_ref[slot_ref] : -1;
@@ -1075,9 +1094,9 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
 #ifndef PTMI_WIDE_WAVES
 #define PTMI_WIDE_WAVES 6
 #endif
-template <bool STATS, bool GUIDED, bool BATCH, bool CERT>
+template <bool STATS, bool GUIDED, bool BATCH, bool CERT, bool QUADS>
 __global__ __launch_bounds__(kBlock, PTMI_WIDE_WAVES) __attribute__((amdgpu_num_sgpr(80))) void ptmi_bounce_wide(BounceArgs a) {
-    bounce_wide_body<STATS, GUIDED, BATCH, CERT>(a);
+    bounce_wide_body<STATS, GUIDED, BATCH, CERT, QUADS>(a);
     publish_count(a);
 }
 
@@ -1159,7 +1178,8 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
         case TRAVERSAL_WIDE:
         case TRAVERSAL_CERTIFIED: {
             const bool cert = sc.traversal == TRAVERSAL_CERTIFIED;
-#define PTMI_WIDE(S_, G_, B_) do { if (cert) f(ptmi_bounce_wide<S_, G_, B_, true>, lds); else f(ptmi_bounce_wide<S_, G_, B_, false>, lds); } while (0)
+#define PTMI_WIDE(S_, G_, B_) do { if (sc.wqprims) { if (cert) f(ptmi_bounce_wide<S_, G_, B_, true, true>, lds); else f(ptmi_bounce_wide<S_, G_, B_, false, true>, lds); } \
+                                   else { if (cert) f(ptmi_bounce_wide<S_, G_, B_, true, false>, lds); else f(ptmi_bounce_wide<S_, G_, B_, false, false>, lds); } } while (0)
             switch ((a.stats ? 4 : 0) | (is_guided(a) ? 2 : 0) | (a.fp.n_frames > 1 ? 1 : 0)) {
                 case 0: PTMI_WIDE(false, false, false); break;
                 case 1: PTMI_WIDE(false, false, true); break;
@@ -1384,7 +1404,14 @@ __global__ __launch_bounds__(kBlock) void ptmi_debug_intersect_wide_k(DeviceScen
             const f3p* r = reinterpret_cast<const f3p*>(sc.wprims) + 3 * (size_t)k;
             const f3p v0 = r[0], e1 = r[1], e2 = r[2];
             float tt = 0.0f;
-            if (mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), ro, rd, 1e-8f, t_lo, tt)) {
+            bool ok;
+            if (sc.wqprims && __float_as_int(sc.wqprims[4 * (size_t)k].w) != 0) {           // a quad: the smaller t of its two halves
+                const float4* q = sc.wqprims + 4 * (size_t)k;
+                const float eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+                tt = min_raw(mt_candidate(xyz(q[0]), xyz(q[1]), xyz(q[2]), ro, rd, eps_up, t_lo), mt_candidate(xyz(q[0]), xyz(q[2]), xyz(q[3]), ro, rd, eps_up, t_lo));
+                ok = tt < __builtin_inff();
+            } else ok = mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), ro, rd, 1e-8f, t_lo, tt);
+            if (ok) {
                 if (tt < closest_t) { closest_t = tt; slot_hit = k; }
                 else if (tt == closest_t && slot_hit >= 0 && sc.wref_slot[k] < sc.wref_slot[slot_hit]) slot_hit = k;
             }

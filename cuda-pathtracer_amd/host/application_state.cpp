@@ -203,7 +203,7 @@ void SceneState::upload() {
     // Triangle scenes beyond the sweep's few dozen primitives: the 8-wide tree + the certificate data of TRAVERSAL_CERTIFIED - the
     // default walk there: the reference's hit for every ray, by proof or by its own walk, at 1.4 - 2.3 x the rate of the walk over
     // the reference's tree (128 ... 1 M triangles, planar scenes included; 1 M triangles: +1.3 s of loading, +145 MB)
-    if (n > sweep_max_prims && !num_quads && bvh_depth <= 62 && certified_default) {
+    if (n > sweep_max_prims && bvh_depth <= 62 && certified_default) {
         try { buildFast(); }
         catch (const ArgError&) { freeFast(); }        // a scene the builder declines (tree deeper than 48): the reference's tree is walked
     }
@@ -320,8 +320,9 @@ void SceneState::buildPacked() {
 }
 
 void SceneState::freeFast() {
-    void* ptrs[] = {d_wnodes, d_wprims, d_wmats, d_wmtab, d_wload_index, d_wref_slot, d_wanc, d_wcert, d_wfast_of_ref};
+    void* ptrs[] = {d_wnodes, d_wprims, d_wmats, d_wmtab, d_wload_index, d_wref_slot, d_wanc, d_wcert, d_wfast_of_ref, d_wqprims};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_wqprims = nullptr; d_scene.wqprims = nullptr;
     d_wnodes = nullptr; d_wprims = nullptr; d_wmats = d_wmtab = nullptr; d_wload_index = d_wref_slot = nullptr;
     d_wanc = nullptr; d_wcert = nullptr; d_wfast_of_ref = nullptr;
     h_wide.clear();
@@ -335,7 +336,6 @@ void SceneState::freeFast() {
 void SceneState::buildFast() {
     freeFast();
     if (!d_nodes) throw ArgError("fast tree: no scene loaded");
-    if (num_quads) throw ArgError("fast tree: triangle scenes only (load with convert_quads)");
     try { buildWideBVH(h_primitives, wide_params, h_wide); }
     catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
     if (h_wide.depth > 48) { h_wide.clear(); throw ArgError("fast tree: deeper than 48 levels"); }
@@ -346,6 +346,7 @@ void SceneState::buildFast() {
     std::map<std::array<uint32_t, 6>, int> rows;
     std::vector<float4> wm((size_t)n), tab;
     std::vector<float> wp((size_t)9 * n);
+    std::vector<float4> wq(num_quads ? (size_t)4 * n : 0);
     for (int k = 0; k < n; k++) {
         const int li = h_wide.tri_load_index[k];
         const Primitive& p = h_primitives[li];
@@ -362,6 +363,13 @@ void SceneState::buildFast() {
         const f3 e1 = p.v[1] - p.v[0], e2 = p.v[2] - p.v[0];             // the float subtraction the reference does per test
         const float rec[9] = {p.v[0].x, p.v[0].y, p.v[0].z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z};
         std::memcpy(&wp[(size_t)9 * k], rec, sizeof rec);
+        if (num_quads) {                                                  // scenes with quads: the 64-byte records of d_prims, fast order
+            const f3 e3 = p.type == PRIM_QUAD ? p.v[3] - p.v[0] : mk3(0, 0, 0);
+            wq[(size_t)4 * k] = make_float4(p.v[0].x, p.v[0].y, p.v[0].z, bits(p.type == PRIM_QUAD ? 1 : 0));
+            wq[(size_t)4 * k + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+            wq[(size_t)4 * k + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+            wq[(size_t)4 * k + 3] = make_float4(e3.x, e3.y, e3.z, 0.0f);
+        }
     }
     auto upload_vec = [&](const void* src, size_t bytes, const char* name) {
         void* d = hipMallocSafe(bytes, name);
@@ -370,6 +378,7 @@ void SceneState::buildFast() {
     };
     d_wnodes = (uint4*)upload_vec(h_wide.nodes.data(), h_wide.nodes.size() * sizeof(uint32_t), "d_wnodes");
     d_wprims = (float*)upload_vec(wp.data(), wp.size() * sizeof(float), "d_wprims");
+    if (num_quads) d_wqprims = (float4*)upload_vec(wq.data(), wq.size() * sizeof(float4), "d_wqprims");
     d_wmats = (float4*)upload_vec(wm.data(), wm.size() * sizeof(float4), "d_wmats");
     d_wmtab = (float4*)upload_vec(tab.data(), tab.size() * sizeof(float4), "d_wmtab");
     d_wload_index = (int*)upload_vec(h_wide.tri_load_index.data(), (size_t)n * sizeof(int), "d_wload_index");
@@ -422,6 +431,7 @@ void SceneState::buildFast() {
     for (size_t l = 1; l < h_wide.level_start.size(); l++)
         if (h_wide.level_start[l] <= wide_top_nodes && (long long)h_wide.level_start[l] * kWideNodeDwords * 4 <= lds_budget) top = h_wide.level_start[l];
     d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = stack_entries;
+    d_scene.wqprims = d_wqprims;
     d_scene.wprims = d_wprims; d_scene.wmats = d_wmats; d_scene.wmtab = d_wmtab; d_scene.wload_index = d_wload_index; d_scene.wref_slot = d_wref_slot;
     d_scene.wanc = d_wanc; d_scene.wcert = d_wcert; d_scene.wfast_of_ref = d_wfast_of_ref; d_scene.w_guard = h_wide.origin_guard; d_scene.w_big = 0.25f * h_wide.origin_guard;
 }
@@ -845,7 +855,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // segment for longer: with the phased kernels' threshold c2 loses 7 %, c3 8 %; at 0.3 x the wave slots a small frame
     // gains (cbox 256^2 +14 %, 362^2 +15 %; 512^2 = 0.5 x the slots -11 % with one launch) and c2's last stretch +0.5 %.
     // the opt-in fast tree: built at the first frame that asks for it; quad scenes keep the exact walk
-    if (g.config.fast_tree && !g.scene.fastReady() && !g.scene.num_quads && g.config.current_integrator == IntegratorType::PathTracing)
+    if (g.config.fast_tree && !g.scene.fastReady() && g.config.current_integrator == IntegratorType::PathTracing)
         g.scene.buildFast();
     DeviceScene scene = g.scene.d_scene;
     if (g.config.fast_tree && g.scene.fastReady()) scene.traversal = TRAVERSAL_WIDE;

@@ -80,6 +80,7 @@ struct SceneState {
     int *d_wload_index = nullptr, *d_wref_slot = nullptr;
     uint4* d_wanc = nullptr;                         // TRAVERSAL_CERTIFIED: ancestor lists of the reference's leaves, see buildFast
     float4* d_wcert = nullptr;
+    float4* d_wqprims = nullptr;
     int* d_wfast_of_ref = nullptr;
     void buildFast();                                // host build + upload; throws ArgError for scenes with quads
     void freeFast();

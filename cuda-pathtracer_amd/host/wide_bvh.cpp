@@ -122,7 +122,7 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
     prm.max_leaf = std::max(1, std::min(prm.max_leaf, kWideMaxLeaf));
     const int n = (int)prims.size();
     if (n == 0) throw std::invalid_argument("fast tree: scene has no primitives");
-    for (const Primitive& p : prims) if (p.type != PRIM_TRIANGLE) throw std::invalid_argument("fast tree: triangle scenes only");
+    auto n_verts = [](const Primitive& p) { return p.type == PRIM_QUAD ? 4 : 3; };
 
     // triangle boxes, padded.  The node test computes a plane distance as fma(q, 2^e / d, (p - o) / d): its error is a few
     // 2^-24 of |p - o| + the node's extent, i.e. of |o| + the scene's largest coordinate `big`.  For origins with |coordinate|
@@ -132,14 +132,14 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
     std::vector<Box> pbox((size_t)n);
     std::vector<std::array<float, 3>> pcen((size_t)n);
     float big = 0.0f;
-    for (const Primitive& p : prims) for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
+    for (const Primitive& p : prims) for (int k = 0; k < n_verts(p); k++) big = std::max(big, std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
     if (!(big < 1.0e9f)) throw std::invalid_argument("fast tree: coordinates must stay below 1e9");
     const float pad = big * (1.0f / 65536.0f) + 1e-6f;
     out.origin_guard = 4.0f * big;
     for (int i = 0; i < n; i++) {
         const Primitive& p = prims[i];
         Box b;
-        for (int k = 0; k < 3; k++) { const float v[3] = {p.v[k].x, p.v[k].y, p.v[k].z}; b.grow(v); }
+        for (int k = 0; k < n_verts(p); k++) { const float v[3] = {p.v[k].x, p.v[k].y, p.v[k].z}; b.grow(v); }
         for (int a = 0; a < 3; a++) { pcen[i][a] = 0.5f * (b.lo[a] + b.hi[a]); b.lo[a] -= pad; b.hi[a] += pad; }
         pbox[i] = b;
     }
@@ -295,8 +295,31 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
 }
 
 namespace {
-// Triangle::intersect (triangle.h:64-96) with precomputed edges, accept test as pt_device.h: mt_accept states it
+// One half of Quad::intersect (quad.h:56-87 / 90-121) without its upper bound: t of the half (v0; v0 + edge1, v0 + edge2) if it
+// is accepted, else +inf.  The inclusive forms of the quad (|a| > eps, u >= 0 && u <= 1, ...), t > eps && t >= t_min as t >= t_lo.
+float quad_half_host(f3 v0, f3 edge1, f3 edge2, f3 o, f3 d, float t_lo) {
+    const float inf = std::numeric_limits<float>::infinity();
+    const f3 h = cross(d, edge2);
+    const float a = dot(edge1, h);
+    if (!(std::fabs(a) > 1e-8f)) return inf;
+    const float f = 1.0f / a;
+    const f3 s = o - v0;
+    const float u = f * dot(s, h);
+    if (!(u >= 0.0f && u <= 1.0f)) return inf;
+    const f3 q = cross(s, edge1);
+    const float v = f * dot(d, q);
+    if (!(v >= 0.0f && u + v <= 1.0f)) return inf;
+    const float t = f * dot(edge2, q);
+    return t >= t_lo ? t : inf;
+}
+// Triangle::intersect (triangle.h:64-96) with precomputed edges, accept test as pt_device.h: mt_accept states it; a quad: the
+// smaller t of its two halves (Quad::intersect under an upper bound c returns exactly that whenever it is below c)
 bool mt_host(const Primitive& p, f3 o, f3 d, float t_lo, float& t) {
+    if (p.type == PRIM_QUAD) {
+        const f3 e1 = p.v[1] - p.v[0], e2 = p.v[2] - p.v[0], e3 = p.v[3] - p.v[0];
+        t = std::fmin(quad_half_host(p.v[0], e1, e2, o, d, t_lo), quad_half_host(p.v[0], e2, e3, o, d, t_lo));
+        return t < std::numeric_limits<float>::infinity();
+    }
     const f3 edge1 = p.v[1] - p.v[0], edge2 = p.v[2] - p.v[0];
     const f3 h = cross(d, edge2);
     const float a = dot(edge1, h);

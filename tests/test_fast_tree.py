@@ -62,7 +62,8 @@ def oracle_hits(o, org, d, t_min=1e-4, t_max=FLT_MAX):
             float(np.mean([h.node_visits for h in hs])), float(np.mean([h.prim_tests for h in hs])))
 
 
-SCENE_CASES = [("cbox", None), ("cbox_sub3", None), ("tess32x16", None), ("soup3000", None), ("soup2", None)]
+SCENE_CASES = [("cbox", None), ("cbox_sub3", None), ("tess32x16", None), ("soup3000", None), ("soup2", None),
+               ("quads_sub3", None), ("mixed_soup", None)]
 
 
 def scene_arrays(name):
@@ -76,6 +77,12 @@ def scene_arrays(name):
         return soup(3000, 5)
     elif name == "soup2":
         return soup(2, 6)
+    elif name == "quads_sub3":                                   # native quads (Quad::intersect's two halves in a wide leaf)
+        p = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj"), 3, False).prims()
+    elif name == "mixed_soup":                                   # triangles and quads in one scene
+        t = soup(1500, 7)
+        q = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj"), 2, False).prims()
+        return tuple(np.concatenate([a, q[k]]) for a, k in zip(t, ("type", "verts", "normal", "bsdf", "Le")))
     return (p["type"], p["verts"], p["normal"], p["bsdf"], p["Le"])
 
 
@@ -99,13 +106,11 @@ def test_host_walk_finds_the_oracles_hits(name, max_leaf):
         assert r["max_stack"] < info["depth"]
 
 
-def test_fast_tree_is_for_triangle_scenes():
+def test_fast_tree_walk_needs_a_built_tree():
     hs = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj"))
-    with pytest.raises(ptmi.PtmiError) as e:
-        hs.fast_tree_build()
-    assert "triangle" in str(e.value)
     with pytest.raises(ptmi.PtmiError):
         hs.fast_tree_intersect(np.zeros((1, 3), F), np.ones((1, 3), F))      # nothing built
+    assert hs.fast_tree_build()["n_nodes"] >= 1                              # quads are fine: a quad is one primitive of a wide leaf
 
 
 def test_coplanar_ties_keep_the_references_choice():
@@ -142,7 +147,7 @@ def R():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cbox", "cbox_sub3", "tess32x16", "soup3000"])
+@pytest.mark.parametrize("name", ["cbox", "cbox_sub3", "tess32x16", "soup3000", "quads_sub3", "mixed_soup"])
 def test_gpu_walk_equals_host_walk(R, name):
     """ptmi_debug_intersect_fast (the kernel's walk) against the host walk: same hits, same t, and the same number of node
     visits and triangle tests in total - the two take the same decisions - and both equal the oracle's hits."""
@@ -403,15 +408,29 @@ def test_certified_walk_sends_what_it_cannot_prove_through_the_references_walk(R
 
 
 @pytest.mark.gpu
-def test_fast_tree_on_a_quad_scene_keeps_the_exact_walk(R):
+@pytest.mark.parametrize("sub", [0, 2, 4])
+def test_quad_scenes_through_the_fast_tree_and_the_certified_walk(R, sub):
+    """Native quads: a quad is ONE primitive of a wide leaf, tested with Quad::intersect's two-half rule (quad.h:56-121).  16
+    quads keep the sweep; 256 and 4096 quads walk CERTIFIED automatically.  Frames through the certified walk, through the fast
+    tree without the proof and through the reference's tree must all be the oracle's (planar scene: no tie or grazing case
+    reaches a pixel here)."""
     path = os.path.join(SCENES, "cbox_quads.obj")
-    R.load_scene(path); R.update_resolution(64, 64)
-    R.set_config(spp=4, max_depth=5, fast_tree=True)
-    R.render_frame()
-    _, rad = R.read_image()
-    _, orad, _ = OracleScene.load(path).render(default_camera(), 64, 64, 4, max_depth=5)
-    assert (bits(rad) == bits(orad)).all()
-    R.set_config(fast_tree=False)
+    R.load_scene(path, sub, False)
+    n = R.scene_info()["n_prims"]
+    o = OracleScene.load(path, sub, False)
+    W, H, spp, depth = 96, 72, 6, 6
+    _, orad, ost = o.render(default_camera(), W, H, spp, max_depth=depth)
+    try:
+        assert R.set_traversal(-1) == (R.CERTIFIED if n > 64 else R.SWEEP)
+        for mode, fast in ((-1, False), (R.CERTIFIED, False), (-1, True), (R.PHASED, False)):
+            R.set_traversal(mode); R.set_config(spp=spp, max_depth=depth, fast_tree=fast, collect_stats=True)
+            R.update_resolution(W, H); st = R.render_frame()
+            assert (bits(R.read_image(rgb8=False)[1]) == bits(orad)).all(), (sub, mode, fast)
+            assert (st.rays, st.hits) == (ost.rays, ost.hits)
+            R.set_config(collect_stats=False); R.update_resolution(W, H); R.render_frame()
+            assert (bits(R.read_image(rgb8=False)[1]) == bits(orad)).all(), (sub, mode, fast, "timing build")
+    finally:
+        R.set_traversal(-1); R.set_config(fast_tree=False, collect_stats=False)
 
 
 @pytest.mark.gpu

@@ -239,7 +239,7 @@ def test_packed_layout_gives_the_same_frame(R, name, sub, conv, sampling):
         assert R.set_traversal(R.PHASED) == R.PHASED
         R.update_resolution(W, H); R.render_frame()
         assert_same_image(*R.read_image(), orgb, orad, "phased")
-        assert R.set_packed_min_nodes(1 << 30) == 0 and R.set_traversal(-1) == (R.PHASED if R.scene_info()["n_quads"] else R.CERTIFIED)   # no packed layout: the certified / the pre-order walk
+        assert R.set_packed_min_nodes(1 << 30) == 0 and R.set_traversal(-1) == R.CERTIFIED   # no packed layout: the certified walk stays the automatic choice
         assert R.set_traversal(R.PACKED) == R.PHASED
     finally:
         R.set_traversal(-1); R.set_packed_min_nodes(8192); R.set_packed_top(512)
@@ -639,7 +639,7 @@ def test_random_soup_frames_match_oracle(R, n, seed, mode):
     rgb, rad = R.read_image()
     orgb, orad, ost = o.render(default_camera(), W, H, spp, max_depth=6, sampling_mode=mode)
     assert_same_image(rgb, rad, orgb, orad, f"soup n={n} mode={mode}")
-    assert (st.rays, st.node_visits, st.prim_tests, st.hits) == (ost.rays, ost.node_visits, ost.prim_tests, ost.hits)
+    assert_same_counters(R, st, ost)
     assert n < 7 or (ost.hits > 500 and rad.max() > 0)
     # and the radiosity pre-pass on the same soup (any-hit walk, quad sampling, culling on arbitrary normals)
     if n <= 400:
