@@ -179,7 +179,7 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
 //     Needs |d_a| > 1e-8 (below that the reference replaces 1 / d by 1e8); otherwise, or within eps of a face: the exact
 //     anyhit_box over the leaf's ancestor list (wanc), leaf first, up to the first box that holds Q with the margin; a box of
 //     that list failing: the reference's own walk for this ray.
-template <bool CERT>
+template <bool CERT, bool QUADS = false>
 __device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 lo, float4 hi, float t, f3 o, f3 d, float max_dist, int slot_a, int slot_b, unsigned int& chain) {
     const f3 q = o + t * d;
     const float big = sc.w_big;
@@ -207,10 +207,10 @@ __device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 
     }
     if (ok && sc.w_cert_debug < 2) return true;
     chain += 0x10000u;
-    return visibility_blocked<false, false>(sc, o, d, max_dist, slot_a, slot_b);
+    return visibility_blocked<QUADS, false>(sc, o, d, max_dist, slot_a, slot_b);
 }
 
-template <bool CERT>
+template <bool CERT, bool QUADS>
 __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float max_dist, int load_a, int load_b,
                                                         int slot_a, int slot_b, unsigned int& chain) {
     const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
@@ -235,6 +235,15 @@ __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, u
             tris &= tris - 1u;
             const int li = sc.wload_index[k];
             if (li == load_a || li == load_b) continue;
+            if (QUADS && __float_as_int(sc.wqprims[4 * (size_t)k].w) != 0) {       // a quad: quad.h:78,110 accept t < t_max only
+                const float4* q = sc.wqprims + 4 * (size_t)k;
+                const float eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+                const float tq = min_raw(mt_candidate(xyz(q[0]), xyz(q[1]), xyz(q[2]), o, d, eps_up, 1e-5f), mt_candidate(xyz(q[0]), xyz(q[2]), xyz(q[3]), o, d, eps_up, 1e-5f));
+                if (!(tq < max_dist)) continue;
+                if (!CERT) return true;
+                const float4 c_lo = sc.wcert[2 * (size_t)k], c_hi = sc.wcert[2 * (size_t)k + 1];
+                return certified_blocked<CERT, QUADS>(sc, c_lo, c_hi, tq, o, d, max_dist, slot_a, slot_b, chain);
+            }
             const float* r = sc.wprims + 9 * (size_t)k;
             const f3 v0 = mk3(r[0], r[1], r[2]), edge1 = mk3(r[3], r[4], r[5]), edge2 = mk3(r[6], r[7], r[8]);
             const f3 h = cross(d, edge2);                                  // anyhit_prim, triangle form
@@ -253,7 +262,7 @@ __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, u
                 if (!CERT) return true;
                 // (fetching the leaf box together with the triangle record, before the test: no gain - n = 8192: 84.0 vs 84.4 ms)
                 const float4 c_lo = sc.wcert[2 * (size_t)k], c_hi = sc.wcert[2 * (size_t)k + 1];
-                return certified_blocked<CERT>(sc, c_lo, c_hi, t, o, d, max_dist, slot_a, slot_b, chain);
+                return certified_blocked<CERT, QUADS>(sc, c_lo, c_hi, t, o, d, max_dist, slot_a, slot_b, chain);
             }
         }
         g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
@@ -319,7 +328,7 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, i
         const f3 ro = p_i + 1e-4f * gi.normal;
         const f3 rd = unit_vector(sample_dir);                                  // Ray's constructor normalises again (ray.h:9-12)
         rays++;
-        const bool blocked = WIDE ? visibility_blocked_wide<WIDE == 2>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
+        const bool blocked = WIDE ? visibility_blocked_wide<WIDE == 2, HAS_QUADS>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
                                   : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j);
         if (!blocked) {
             visibility_sum += 1.0f; cos_i_sum += cos_theta_i; cos_j_sum += cos_theta_j; dist_sum += r;
@@ -358,7 +367,7 @@ __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, 
     const f3 ro = gi.centroid + 1e-4f * gi.normal;
     const f3 rd = unit_vector(dir_ij);
     rays++;
-    if (WIDE ? visibility_blocked_wide<WIDE == 2>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
+    if (WIDE ? visibility_blocked_wide<WIDE == 2, HAS_QUADS>(sc, wstack, ro, rd, r - 2e-4f, i, j, slot_i, slot_j, chain)
              : visibility_blocked<HAS_QUADS, DEEP>(sc, ro, rd, r - 2e-4f, slot_i, slot_j)) return 0.0f;
     const float ff = (float)((double)(cos_theta_i * cos_theta_j * gj.area) / (PTMI_PI_D * (double)r * (double)r));
     return fmaxf(0.0f, ff);
@@ -802,16 +811,17 @@ __global__ __launch_bounds__(kBlock) void ptmi_cdf_records(const void* __restric
 
 template <bool MC, bool Q_, bool D_>
 void launch_ff3(bool rad0, dim3 grid, hipStream_t s, const DeviceScene& sc, const RadiosityBuffers& rb, int n_samples, const uint32_t* jump) {
-    if constexpr (!Q_ && !D_) {
+    if constexpr (!D_) {
         const size_t lds = (size_t)sc.w_depth * kBlock * sizeof(uint2);
-        if (rb.fast_tree == 1 && sc.wnodes) {              // the opt-in fast tree for the visibility walk, no certificate
-            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
-            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+        const bool records = Q_ ? sc.wqprims != nullptr : sc.wprims != nullptr;
+        if (rb.fast_tree == 1 && sc.wnodes && records) {   // the opt-in fast tree for the visibility walk, no certificate
+            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, false, true, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, false, false, 1>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
             return;
         }
-        if (rb.fast_tree == 2 && sc.wnodes && sc.wcert && sc.wanc) {   // the certified walk: the reference's answers, through the fast tree
-            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, true, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
-            else hipLaunchKernelGGL((ptmi_form_factors<MC, false, false, false, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+        if (rb.fast_tree == 2 && sc.wnodes && records && sc.wcert && sc.wanc) {   // the certified walk: the reference's answers, through the fast tree
+            if (MC && rad0) hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, false, true, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
+            else hipLaunchKernelGGL((ptmi_form_factors<MC, Q_, false, false, 2>), grid, dim3(kBlock), lds, s, sc, rb, n_samples, jump);
             return;
         }
     }

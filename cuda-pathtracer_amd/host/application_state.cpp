@@ -501,7 +501,7 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
     // certified walk - the fast tree + a per-ray proof that the reference's any-hit walk gives the same answer (radiosity.hip:
     // certified_blocked) - the default for triangle scenes from cert_min_prims primitives up; trees are built on first use
     {
-        const bool can = !scene.num_quads && scene.bvh_depth <= 30;
+        const bool can = scene.bvh_depth <= 30;
         int walk = 0;
         if (can && fast_tree) walk = 1;
         else if (can && (force_walk >= 2 || (force_walk < 0 && scene.certified_default && n >= cert_min_prims))) walk = 2;

@@ -278,9 +278,16 @@ def test_radiosity_solver_certified_walk_is_the_references(R):
                 if walk == -1: assert st.cert_fallback <= st.cert_chain < st.rays // 10
         R.set_solver_walk(-1, 1 << 20)
         assert R.run_radiosity_solver(num_iterations=1).walk == 0                  # below the threshold: the reference's walk
-        R.load_scene(os.path.join(SCENES, "cbox_quads.obj"), 3, False)             # quads: no fast tree
-        R.set_solver_walk(2)
-        assert R.run_radiosity_solver(num_iterations=1).walk == 0
+        # native quads (1024 of them): certified too, and the whole solution the reference walk's
+        R.load_scene(os.path.join(SCENES, "cbox_quads.obj"), 3, False)
+        R.set_solver_walk(0); st0 = R.run_radiosity_solver(num_iterations=2); want = R.radiosity_solution()
+        for walk in (-1, 3, 4):
+            R.set_solver_walk(walk); st = R.run_radiosity_solver(num_iterations=2); got = R.radiosity_solution()
+            print(f"certified solver walk {walk}, quads: {st.rays} rays, {st.cert_chain} chains, {st.cert_fallback} fallbacks, "
+                  f"form factors {st.form_factor_ms:.2f} ms (reference's walk {st0.form_factor_ms:.2f} ms)")
+            assert st.walk == 2 and st0.walk == 0 and st.rays == st0.rays
+            for k in ("form_factors", "radiosity", "unshot", "grid", "radiosity_grid"):
+                assert (bits(got[k]) == bits(want[k])).all(), (walk, "quads", k)
     finally:
         R.set_solver_walk(-1)
 
