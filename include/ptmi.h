@@ -89,14 +89,14 @@ typedef struct {
                                    * ctx's pinned host image (RenderState::h_image, application.h:211) - read it through
                                    * ptmi_host_image.  0 (default): results stay on the device until asked for */
     int      fast_tree;           /* 0 (default): every ray's hit is the one the reference's walk over its own tree
-                                   * (rendering/bvh.h:156-218) returns - frames bit-identical to the reference's.  (Triangle scenes
-                                   * above 64 primitives get there through an 8-wide binned-SAH tree plus a per-ray proof, else the
+                                   * (rendering/bvh.h:156-218) returns - frames bit-identical to the reference's.  (Scenes above
+                                   * 64 primitives get there through an 8-wide binned-SAH tree plus a per-ray proof, else the
                                    * reference's walk for that ray: the certified walk)  1: opt-in, the same tree
-                                   * WITHOUT the proof (last bullet; about 7 % faster): triangles, hit arithmetic, RNG
-                                   * draws and shading are untouched; a ray's hit can differ only where two triangles are hit at
+                                   * WITHOUT the proof (last bullet; about 7 % faster): primitives, hit arithmetic, RNG
+                                   * draws and shading are untouched; a ray's hit can differ only where two primitives are hit at
                                    * exactly the same t or where the reference's own slab test drops a grazing box
-                                   * (cuda-pathtracer_amd/csrc/wide_bvh.h: 1 pixel of 4 M on a 1 M-triangle frame).  Scenes with
-                                   * quads keep the reference's tree.  ptmi_run_radiosity_solver reads the switch too: its
+                                   * (cuda-pathtracer_amd/csrc/wide_bvh.h: 1 pixel of 4 M on a 1 M-triangle frame).
+                                   * ptmi_run_radiosity_solver reads the switch too: its
                                    * visibility walk (form_factors.h:143-208) then skips the proof as well (n = 8192: 84 -> 71 ms;
                                    * 2 of 67 M form factors differ) */
 } ptmi_config;
@@ -322,7 +322,7 @@ int ptmi_debug_place_tiles(ptmi_ctx*, int width, int height, int n_ranks, int ro
  * 4 = 3 over the packed layout (sibling-pair node order, 36-byte triangles; only where that layout was built, else 3);
  * 6 = certified: the 8-wide tree of ptmi_config.fast_tree + a per-ray proof that the reference's walk returns the same hit,
  *     else the reference's walk for that ray (results identical, the node / test counters are its own) - the automatic choice
- *     of every triangle scene above sweep_max_prims whose tree is no deeper than 62;
+ *     of every scene above sweep_max_prims whose tree is no deeper than 62;
  * sweep_max_prims = largest scene (primitives)
  * the automatic choice still sweeps (default 64).  Trees deeper than 62 always use the stack walk.
  * out_mode (may be NULL) receives the mode now in effect for the loaded scene, or -1 without a scene. */
@@ -348,7 +348,7 @@ int ptmi_debug_intersect(ptmi_ctx*, int n, const float* o, const float* d, float
                          int* hit, int* prim, float* t, float* p, float* nrm);
 /* The opt-in fast tree (ptmi_config.fast_tree; cuda-pathtracer_amd/csrc/wide_bvh.h).  Builder knobs: max_leaf 1..3 triangles per
  * leaf child (default 3), c_trav / c_tri = SAH cost of a box level / a triangle test (1, 1), top_nodes = whole levels kept in
- * LDS while they fit this many 128-byte nodes (80).  Rebuilds the loaded scene's fast tree at once (triangle scenes only) and
+ * LDS while they fit this many 128-byte nodes (80).  Rebuilds the loaded scene's fast tree at once and
  * applies to later loads; any out pointer may be NULL. */
 int ptmi_debug_set_fast_tree(ptmi_ctx*, int max_leaf, float c_trav, float c_tri, int top_nodes, int* n_nodes, int* depth, int* n_top);
 /* Closest hit through the fast tree for n rays as given (the walk of ptmi_bounce_wide).  prim: load-order index or -1;
