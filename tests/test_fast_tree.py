@@ -441,6 +441,19 @@ def test_quad_scenes_through_the_fast_tree_and_the_certified_walk(R, sub):
 
 
 @pytest.mark.gpu
+def test_certified_walk_soak_against_the_reference_tree_on_the_gpu():
+    """tools/certified_soak.py: random soups of triangles and skewed quads (65 .. 20 000 primitives; generic, triangles only,
+    axis-aligned = flat boxes everywhere, every primitive twice = every hit a tie), random and far-away cameras, path tracing and
+    the radiosity pre-pass: the automatic (certified) walk and the walk over the reference's tree must agree bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "certified_soak.py"), "12", "7"], capture_output=True, text=True, timeout=900)
+    print(p.stdout[-1500:])
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "12 scenes: 0 mismatches" in p.stdout
+
+
+@pytest.mark.gpu
 def test_fast_tree_config5_rows(R):
     """BASELINE configs[4] (1,048,576 triangles, 2048^2, depth 8): the rows the exact test renders (tests/test_gpu_fullsize.py),
     through the fast tree: #pixels that differ from the oracle, max abs and RMSE are reported; the bar is RMSE < 1e-4."""
