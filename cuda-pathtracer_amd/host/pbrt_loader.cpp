@@ -120,43 +120,57 @@ struct Token {
     std::string text;
     explicit operator bool() const { return type != NONE; }
 };
+// The token grammar of impl/syntactic/Lexer.inl as a table-driven scanner over the whole file text: every byte belongs to one of
+// five classes, and a token is a RUN - blanks and comments are skipped with one search each, a string is the span up to the next
+// quote, a literal the maximal run of "word" bytes.  Tokens: "..." (no escapes), one of [ , ] alone, or a literal that ends before
+// the next blank, #, quote or bracket.  A comment runs to the end of its line; an unterminated one ends the input.
 struct Lexer {
+    enum Class : unsigned char { WORD = 0, BLANK, HASH, QUOTE, BRACKET };
+    struct Table { unsigned char cls[256]; };
+    static const Table& table() {
+        static const Table t = [] {
+            Table x{};
+            for (unsigned char c : {' ', '\n', '\t', '\r'}) x.cls[c] = BLANK;
+            x.cls[(unsigned char)'#'] = HASH; x.cls[(unsigned char)'"'] = QUOTE;
+            for (unsigned char c : {'[', ',', ']'}) x.cls[c] = BRACKET;
+            return x;
+        }();
+        return t;
+    }
     std::string buf; size_t pos = 0;
     explicit Lexer(const std::string& file) {
         std::ifstream in(file, std::ios::binary);
         if (!in) throw PbrtError("could not open '" + file + "'");
         std::ostringstream ss; ss << in.rdbuf(); buf = ss.str();
     }
-    int get() { return pos < buf.size() ? (unsigned char)buf[pos++] : -1; }
-    static bool white(int c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
-    static bool special(int c) { return c == '[' || c == ',' || c == ']'; }
+    Class at(size_t i) const { return (Class)table().cls[(unsigned char)buf[i]]; }
     Token next() {
-        int c;
-        while (true) {
-            c = get();
-            if (c < 0) return Token();
-            if (white(c)) continue;
-            if (c == '#') { while (c != '\n') { c = get(); if (c < 0) return Token(); } continue; }
-            break;
+        const size_t n = buf.size();
+        while (pos < n) {                                  // between tokens: blanks and whole comment lines
+            if (at(pos) == BLANK) { pos++; continue; }
+            if (at(pos) != HASH) break;
+            const size_t eol = buf.find('\n', pos);
+            pos = eol == std::string::npos ? n : eol + 1;
+            if (eol == std::string::npos) return Token();
         }
+        if (pos >= n) return Token();
         Token t;
-        if (c == '"') {
-            while (true) {
-                c = get();
-                if (c < 0) throw PbrtError("could not find end of string literal (found eof instead)");
-                if (c == '"') break;
-                t.text.push_back((char)c);
+        switch (at(pos)) {
+            case QUOTE: {
+                const size_t close = buf.find('"', pos + 1);
+                if (close == std::string::npos) throw PbrtError("string literal without a closing quote");
+                t.type = Token::STRING; t.text.assign(buf, pos + 1, close - pos - 1); pos = close + 1;
+                return t;
             }
-            t.type = Token::STRING; return t;
-        }
-        t.text.push_back((char)c);
-        if (special(c)) { t.type = Token::SPECIAL; return t; }
-        t.type = Token::LITERAL;
-        while (true) {
-            c = get();
-            if (c < 0) return t;
-            if (c == '#' || special(c) || white(c) || c == '"') { pos--; return t; }
-            t.text.push_back((char)c);
+            case BRACKET:
+                t.type = Token::SPECIAL; t.text.assign(1, buf[pos++]);
+                return t;
+            default: {
+                size_t end = pos + 1;
+                while (end < n && at(end) == WORD) end++;
+                t.type = Token::LITERAL; t.text.assign(buf, pos, end - pos); pos = end;
+                return t;
+            }
         }
     }
 };
@@ -178,62 +192,35 @@ struct ParamSet {
     const Param* findKind(const std::string& n, Param::Kind k) const { const Param* p = find(n); return p && p->kind == k ? p : nullptr; }
     bool hasTexture(const std::string& n) const { return findKind(n, Param::TEXTURE) != nullptr; }
     bool hasNf(const std::string& n, size_t N) const { const Param* p = findKind(n, Param::FLOAT); return p && p->f.size() == N; }
-    // the throwing accessors of ParamSet (impl/syntactic/Scene.cpp:141-330): present but of the wrong kind or size is an error
-    bool get3f(float* out, const std::string& n) const {
-        const Param* p = find(n);
-        if (!p) return false;
-        if (p->kind != Param::FLOAT) throw PbrtError("found param of given name, but of wrong type! (name was '" + n + "'");
-        if (p->f.size() != 3) throw PbrtError("found param of given name and type, but wrong number of components! (3f, name='" + n + "'");
-        out[0] = p->f[0]; out[1] = p->f[1]; out[2] = p->f[2];
-        return true;
-    }
-    bool get2f(float* out, const std::string& n) const {
-        const Param* p = find(n);
-        if (!p) return false;
-        if (p->kind != Param::FLOAT) throw PbrtError("found param of given name, but of wrong type! (name was '" + n + "'");
-        if (p->f.size() != 2) throw PbrtError("found param of given name and type, but wrong number of components! (2f, name='" + n + "'");
-        out[0] = p->f[0]; out[1] = p->f[1];
-        return true;
-    }
-    float get1f(const std::string& n, float fallback = 0) const {
-        const Param* p = find(n);
-        if (!p) return fallback;
-        if (p->kind != Param::FLOAT) throw PbrtError("1f: found param of given name, but of wrong type! (name was '" + n + "'");
-        if (p->f.size() != 1) throw PbrtError("found param of given name and type, but wrong number of components!");
-        return p->f[0];
-    }
-    int get1i(const std::string& n, int fallback = 0) const {
-        const Param* p = find(n);
-        if (!p) return fallback;
-        if (p->kind != Param::INT) throw PbrtError("1i: found param of given name (" + n + "), but of wrong type!");
-        if (p->i.size() != 1) throw PbrtError("found param of given name and type, but wrong number of components! (1i, name='" + n + "'");
-        return p->i[0];
-    }
-    bool getBool(const std::string& n, bool fallback = false) const {
-        const Param* p = find(n);
-        if (!p) return fallback;
-        if (p->kind != Param::BOOL) throw PbrtError("bool: found param of given name (" + n + "), but of wrong type!");
-        if (p->b.size() != 1) throw PbrtError("found param of given name and type, but wrong number of components! (bool, name='" + n + "'");
-        return p->b[0];
-    }
-    std::string getString(const std::string& n) const {
-        const Param* p = find(n);
-        if (!p) return "";
-        if (p->kind != Param::STRING) throw PbrtError("str: found param of given name (" + n + "), but of wrong type!");
-        if (p->s.size() != 1) throw PbrtError("found param of given name and type, but wrong number of components! (str, name='" + n + "'");
-        return p->s[0];
-    }
-    std::shared_ptr<TextureDecl> getTexture(const std::string& n) const {
+    // The accessors of ParamSet (impl/syntactic/Scene.cpp:141-330) share one rule: an absent parameter is "not there" (the caller's
+    // fallback), a parameter of another kind or of the wrong length fails the load.  `count` 0 = any length.
+    const Param* expect(const std::string& n, Param::Kind kind, size_t count) const {
+        static const char* const names[] = {"float", "integer", "bool", "string", "texture"};
         const Param* p = find(n);
         if (!p) return nullptr;
-        if (p->kind != Param::TEXTURE) throw PbrtError("tex: found param of given name (" + n + "), but of wrong type!");
-        return p->texture;
+        if (p->kind != kind) throw PbrtError("parameter '" + n + "' is a " + names[p->kind] + ", a " + names[kind] + " was asked for");
+        if (count && p->size() != count)
+            throw PbrtError("parameter '" + n + "' holds " + std::to_string(p->size()) + " values where " + std::to_string(count) + " are required");
+        return p;
     }
-    void getPairNf(const std::string& n) const {
-        const Param* p = find(n);
-        if (!p) return;
-        if (p->kind != Param::FLOAT) throw PbrtError("found param of given name, but of wrong type! (name was '" + n + "'");
-        if (p->f.size() % 2 != 0) throw PbrtError("found param of given name and type, but components aren't pairs! (PairNf, name='" + n + "'");
+    bool get3f(float* out, const std::string& n) const {
+        const Param* p = expect(n, Param::FLOAT, 3);
+        if (p) std::copy(p->f.begin(), p->f.end(), out);
+        return p != nullptr;
+    }
+    bool get2f(float* out, const std::string& n) const {
+        const Param* p = expect(n, Param::FLOAT, 2);
+        if (p) std::copy(p->f.begin(), p->f.end(), out);
+        return p != nullptr;
+    }
+    float get1f(const std::string& n, float fallback = 0) const { const Param* p = expect(n, Param::FLOAT, 1); return p ? p->f[0] : fallback; }
+    int get1i(const std::string& n, int fallback = 0) const { const Param* p = expect(n, Param::INT, 1); return p ? p->i[0] : fallback; }
+    bool getBool(const std::string& n, bool fallback = false) const { const Param* p = expect(n, Param::BOOL, 1); return p ? (bool)p->b[0] : fallback; }
+    std::string getString(const std::string& n) const { const Param* p = expect(n, Param::STRING, 1); return p ? p->s[0] : std::string(); }
+    std::shared_ptr<TextureDecl> getTexture(const std::string& n) const { const Param* p = expect(n, Param::TEXTURE, 0); return p ? p->texture : nullptr; }
+    void getPairNf(const std::string& n) const {                      // a list of (x, y) pairs: an odd number of floats fails the load
+        const Param* p = expect(n, Param::FLOAT, 0);
+        if (p && p->f.size() % 2 != 0) throw PbrtError("parameter '" + n + "' holds an odd number of floats where pairs are required");
     }
 };
 struct Scope;
