@@ -188,6 +188,8 @@ struct RadiosityBuffers {
     unsigned int* grid = nullptr;      // n * 256 visible-sample counts (Triangle/Quad::grid; integers, so exact in any order)
     float4* rad_grid = nullptr;        // n * 256 (rgb, 0)  (Triangle/Quad::radiosity_grid)
     unsigned long long* rays = nullptr;   // shadow rays cast (1 counter)
+    uint32_t* row_jump = nullptr;      // Monte-Carlo form factors: per receiver i the GF(2) matrix T^(2^67 * (i * n)) (160 rows x 5 words), the part
+                                       // of a pair's XORWOW skip-ahead that all pairs of row i share (ptmi_ff_row_jumps); nullptr: not used
     int n = 0;
     int bvh_depth = 0;                 // > 30: the visibility walk keeps the reference's explicit stack and drop rule
     int fast_tree = 0;                 // the visibility walk: 0 the reference's, 1 DeviceScene's fast tree (opt-in), 2 the certified walk
