@@ -154,11 +154,17 @@ int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool sta
 // (host-mapped pinned memory; the host polls it), zeroes *next_count (the next launch's counter) and *done_count (its own
 // arrival counter): no fill or copy command between two launches of a chunk.  All three nullptr: the host resets and reads.
 struct CountPublish { int* done_count = nullptr; int* next_count = nullptr; int* host_count = nullptr; };
+// Scheduling of one launch; it does not change a result.  max_waves > 0 (with cursor: a device int the caller zeroed): the launch
+// has at most max_waves waves, and a lane whose pixel has had its visit (all samples done, or `segments` segments in this launch)
+// takes the next queue entry no lane has taken yet - one atomicAdd on *cursor per scheduling decision with ending lanes.  With
+// max_waves = the waves the device holds at once, no wave of a launch waits for a slot and no lane idles while pixels are queued.
+// (The 8-wide walks; other kernels ignore it.)
+struct LaunchSchedule { int max_waves = 0; int* cursor = nullptr; };
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */,
                    bool many_waves /* more waves than bounce_resident_waves(): an 8-wave build where there is one */, hipStream_t s,
-                   const CountPublish& pub = CountPublish());
+                   const CountPublish& pub = CountPublish(), const LaunchSchedule& sched = LaunchSchedule());
 // render_radiosity (integrator.h:460-504): the alternative "Radiosity" integrator of renderFrame (application.h:193-197):
 // spp camera rays per pixel, first hit only, Le + per-primitive radiosity, sqrt gamma, 8-bit (+ float mean).
 void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,

@@ -357,6 +357,9 @@ struct BounceArgs {
     int* done_count;                        // workgroups of this launch that have finished (device memory, zero between launches)
     int* next_count;                        // the counter the next launch of this chunk will add to
     int* host_count;                        // pinned host memory, device address
+    // cursor != nullptr: queue entries beyond the launch's threads are handed out through *cursor (zero at launch) to lanes whose
+    // pixel has finished (the 8-wide walks; LaunchSchedule::refill_waves)
+    int* cursor;
 };
 
 // Per-lane path registers (the 88-byte HBM record, unpacked).
@@ -596,9 +599,9 @@ __device__ __forceinline__ float4* stage_scene(const DeviceScene& sc, float4* ld
 
 // kernel tail shared by both bounce kernels: active-path compaction (one atomic per wave reserves queue space, lanes
 // scatter by prefix popcount) and the optional workload counters
-template <bool STATS>
+template <bool STATS, bool COMPACT = true>
 __device__ __forceinline__ void finish_launch(const BounceArgs& a, bool alive, int slot, const LaneCounters& cn) {
-    {
+    if (COMPACT) {
         const unsigned long long mask = __ballot(alive);
         const int lane = threadIdx.x & 63;
         int base = 0;
@@ -654,13 +657,13 @@ __device__ __forceinline__ void bounce_body(const BounceArgs& a) {
     static_assert(MODE != TRAVERSAL_SWEEP || LDS_GEOM, "the sweep reads the scene through LDS broadcasts");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < n_in;
     const float4 *nodes, *prims, *mats;
     float4* lds = stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
     int* stack = reinterpret_cast<int*>(lds) + threadIdx.x;
     if (GUIDED) fill_grid_solid_angles();
 
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < n_in;
     const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
     bool alive = active;
     PathRegs p = {};
@@ -711,6 +714,8 @@ __device__ __forceinline__ void bounce_phased_body(const BounceArgs& a) {
     static_assert(!(PACKED && LDS_GEOM), "the packed layout is for scenes that do not fit LDS");
     const int n_in = a.count_in ? *a.count_in : a.n_in;
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < n_in;
     const float4 *nodes, *prims, *mats;
     stage_scene<LDS_GEOM>(a.sc, smem, nodes, prims, mats);
     if (PACKED) nodes = a.sc.gnodes;
@@ -722,8 +727,6 @@ __device__ __forceinline__ void bounce_phased_body(const BounceArgs& a) {
     const MatSource ms = PACKED ? MatSource{a.sc.gmats, a.sc.mtab, a.sc.load_index} : MatSource{mats, nullptr, nullptr};
     if (GUIDED) fill_grid_solid_angles();
 
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < n_in;
     const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
     bool alive = active;
     PathRegs p = {};
@@ -869,11 +872,21 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 #ifndef PTMI_QUAD_BATCH
 #define PTMI_QUAD_BATCH 2
 #endif
+#ifdef PTMI_TRACE_WAVES
+// experiment-only build (tools/wide_trace.py): one 12-word record per wave of ptmi_bounce_wide - start (wall_clock64, low word),
+// duration in ticks, decisions and lanes advanced per kind (NODE / PRIM / SHADE), shader clocks per kind, lanes the wave started with
+constexpr unsigned int kWideTraceCap = 1u << 19;
+__device__ unsigned int g_wt_n;
+__device__ unsigned int g_wt[kWideTraceCap * 12];
+#endif
 template <bool STATS, bool GUIDED, bool BATCH, bool CERT, bool QUADS>
 __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
+    PTMI_TR(const unsigned long long wt_t0 = (unsigned long long)wall_clock64(); unsigned int wt_n[3] = {0, 0, 0}, wt_l[3] = {0, 0, 0}; unsigned long long wt_c[3] = {0, 0, 0};)
     const int n_in = a.count_in ? *a.count_in : a.n_in;
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < n_in;
     const int n_top = a.sc.w_top;
     uint4* top = reinterpret_cast<uint4*>(smem);
     for (int i = threadIdx.x; i < 8 * n_top; i += kBlock) top[i] = a.sc.wnodes[i];
@@ -888,9 +901,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     const MatSource ms = MatSource{a.sc.wmats, a.sc.wmtab, a.sc.wload_index};
     if (GUIDED) fill_grid_solid_angles();
 
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < n_in;
-    const int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
+    int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
     bool alive = active;
     PathRegs p = {};
     if (active) load_path(a.st, a.tm, slot, p);
@@ -930,6 +941,8 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
         // the proof cost a wave iteration per ray and its stragglers waited for a majority: c5tile 1 407 -> 1 455 Msamples/s
         const int c_shade = __popcll(__ballot(phase == PH_SHADE || (CERT && phase >= PH_VERIFY)));
         if (c_node + c_prim + c_shade == 0) break;
+        PTMI_TR(const int wt_k = c_node >= c_prim && c_node >= c_shade ? 0 : c_prim >= c_shade ? 1 : 2; const long long wt_a = clock64();
+                wt_n[wt_k]++; wt_l[wt_k] += wt_k == 0 ? c_node : wt_k == 1 ? c_prim : c_shade;)
         if (c_node >= c_prim && c_node >= c_shade) {
             if (phase == PH_NODE) {
                 if ((g_bits & 0xffu) == 0u) { sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y; }
@@ -1077,9 +1090,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
             if (phase == PH_SHADE) {
                 const bool more = shade_step<STATS, GUIDED, true, BATCH>(a.fp, a.tm, ms, a.sc.cdfs, p, slot_hit >= 0, closest_t, slot_hit, cn, slot);
                 segs_left--;
-                if (!more) { alive = false; phase = PH_DONE; }
-                else if (segs_left == 0) phase = PH_DONE;
-                else {
+                if (more && segs_left != 0) {                          // the next segment of this pixel
                     slot_hit = -1; closest_t = FLT_MAX; sp = 0; t_mask = 0u;
                     inv = mk3(wide_inv(p.d.x), wide_inv(p.d.y), wide_inv(p.d.z));
                     octinv = wide_octinv(inv);
@@ -1087,13 +1098,57 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     phase = PH_NODE;
                     if (STATS) cn.rays++;
                     if (CERT && !origin_in_range()) phase = PH_EXACT;
+                } else {
+                    // This pixel's visit is over: all its samples are done, or it has had its a.segments segments of this launch.
+                    // Its state goes back to HBM; a pixel that is not through joins the output queue; and when the launch has
+                    // fewer lanes than queue entries (BounceArgs::cursor) the lane takes the next entry no lane has taken yet.  The
+                    // lanes whose visits end in this step share one atomicAdd per counter.
+                    store_path(a.st, slot, p);
+                    const int lane = threadIdx.x & 63;
+                    const unsigned long long ending = __ballot(1), surviving = __ballot(more);
+                    const int first = __ffsll((long long)ending) - 1;
+                    int out_base = 0, in_base = 0;
+                    if (lane == first) {
+                        if (surviving) out_base = atomicAdd(a.count_out, __popcll(surviving));
+                        if (a.cursor) in_base = atomicAdd(a.cursor, __popcll(ending));
+                    }
+                    out_base = __shfl(out_base, first); in_base = __shfl(in_base, first);
+                    if (more) a.queue_out[out_base + __popcll(surviving & ((1ull << lane) - 1ull))] = slot;
+                    const int entry = (int)(gridDim.x * kBlock) + in_base + __popcll(ending & ((1ull << lane) - 1ull));
+                    phase = PH_DONE;
+                    if (a.cursor && entry < n_in) {
+                        slot = a.queue_in ? a.queue_in[entry] : entry;
+                        load_path(a.st, a.tm, slot, p);
+                        segs_left = a.segments;
+                        slot_hit = -1; closest_t = FLT_MAX; sp = 0; t_mask = 0u;
+                        inv = mk3(wide_inv(p.d.x), wide_inv(p.d.y), wide_inv(p.d.z));
+                        octinv = wide_octinv(inv);
+                        g_base = 0u; g_bits = (1u << 8) | (1u << octinv);
+                        phase = PH_NODE;
+                        if (STATS) cn.rays++;
+                        if (CERT && !origin_in_range()) phase = PH_EXACT;
+                    }
                 }
             }
         }
+        PTMI_TR(wt_c[wt_k] += (unsigned long long)(clock64() - wt_a);)
     }
 
-    if (active) store_path(a.st, slot, p);
-    finish_launch<STATS>(a, alive, slot, cn);
+    finish_launch<STATS, false>(a, false, slot, cn);      // every visit has banked its pixel and queued it if it goes on: counters only
+#ifdef PTMI_TRACE_WAVES
+    {
+        const unsigned int lanes0 = (unsigned int)__popcll(__ballot(active));
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned int i = atomicAdd(&g_wt_n, 1u);
+            if (i < kWideTraceCap) {
+                unsigned int* w = g_wt + 12 * (size_t)i;
+                w[0] = (unsigned int)wt_t0; w[1] = (unsigned int)((unsigned long long)wall_clock64() - wt_t0);
+                w[2] = wt_n[0]; w[3] = wt_l[0]; w[4] = wt_n[1]; w[5] = wt_l[1]; w[6] = wt_n[2]; w[7] = wt_l[2];
+                w[8] = (unsigned int)(wt_c[0] >> 4); w[9] = (unsigned int)(wt_c[1] >> 4); w[10] = (unsigned int)(wt_c[2] >> 4); w[11] = lanes0;
+            }
+        }
+    }
+#endif
 }
 #ifndef PTMI_WIDE_WAVES
 #define PTMI_WIDE_WAVES 6
@@ -1105,6 +1160,17 @@ __global__ __launch_bounds__(kBlock, PTMI_WIDE_WAVES) __attribute__((amdgpu_num_
 }
 
 #ifdef PTMI_TRACE_WAVES
+// copies up to cap records (12 words each) of the wide walk's wave trace to out, returns how many there were, and clears
+extern "C" long long ptmi_wide_trace_read(unsigned int* out, long long cap) {
+    unsigned int n = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wt_n), sizeof n) != hipSuccess) return -1;
+    const unsigned int m = n < kWideTraceCap ? n : kWideTraceCap;
+    const long long k = (long long)m < cap ? (long long)m : cap;
+    if (k > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wt), (size_t)k * 12 * sizeof(unsigned int)) != hipSuccess) return -1;
+    const unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wt_n), &z, sizeof z) != hipSuccess) return -1;
+    return (long long)n;
+}
 extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and clears the counters
     unsigned long long z[16] = {};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(z)) != hipSuccess) return -1;
@@ -1205,18 +1271,23 @@ static void with_bounce_kernel(const BounceArgs& a, F&& f) {
 
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
-                   StatCounters* stats, bool many_waves, hipStream_t s, const CountPublish& pub) {
+                   StatCounters* stats, bool many_waves, hipStream_t s, const CountPublish& pub, const LaunchSchedule& sched) {
     if (n_in <= 0) return;
     BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats, many_waves ? 1 : 0,
-                 pub.done_count, pub.next_count, pub.host_count};
-    const dim3 grid((n_in + kBlock - 1) / kBlock);
+                 pub.done_count, pub.next_count, pub.host_count, nullptr};
+    dim3 grid((n_in + kBlock - 1) / kBlock);
+    const bool wide = sc.traversal == TRAVERSAL_WIDE || sc.traversal == TRAVERSAL_CERTIFIED;
+    if (wide && sched.max_waves > 0 && sched.cursor) {      // fewer lanes than queue entries: the lanes take the rest through the cursor
+        a.cursor = sched.cursor;
+        grid.x = std::min<unsigned int>(grid.x, (unsigned int)(sched.max_waves + kBlock / 64 - 1) / (kBlock / 64));
+    }
     with_bounce_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 
 // waves of the frame's bounce kernel that the device holds at once (0: unknown)
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
     BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr, 0,
-                 nullptr, nullptr, nullptr};
+                 nullptr, nullptr, nullptr, nullptr};
     int blocks = 0;
     with_bounce_kernel(a, [&](auto kernel, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;

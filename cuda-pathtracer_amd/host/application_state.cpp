@@ -726,8 +726,9 @@ void RenderState::allocateBuffers() {
         ch.d_queue_init = (int*)hipMallocSafe(cap, "chunk.queue_init");
         ch.d_queue[0] = (int*)hipMallocSafe(cap, "chunk.queue0");
         ch.d_queue[1] = (int*)hipMallocSafe(cap, "chunk.queue1");
-        ch.d_count = (int*)hipMallocSafe((kCountRing + 1) * sizeof(int), "chunk.count");      // + the launch's arrival counter
-        PTMI_HIP(hipMemset(ch.d_count, 0, (kCountRing + 1) * sizeof(int)));
+        // per ring slot i: [2 i] the launch's output count, [2 i + 1] its refill cursor; [2 kCountRing]: the launch's arrival counter
+        ch.d_count = (int*)hipMallocSafe((2 * kCountRing + 1) * sizeof(int), "chunk.count");
+        PTMI_HIP(hipMemset(ch.d_count, 0, (2 * kCountRing + 1) * sizeof(int)));
         // coherent (fine-grained) host memory: with count publishing the device stores into it while the kernel runs
         PTMI_HIP(hipHostMalloc((void**)&ch.h_count, kCountRing * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
         PTMI_HIP(hipHostGetDevicePointer((void**)&ch.d_hcount, ch.h_count, 0));
@@ -897,6 +898,13 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // time behind the other chunk's kernel, not GPU time the frame is short of.  Off by default; PTMI_PUBLISH=1 turns it on.
     bool publish = false;
     if (const char* e = getenv("PTMI_PUBLISH")) publish = e[0] == '1';
+    // Refill (device_scene.h: LaunchSchedule): a launch of the 8-wide walks has at most as many waves as the device holds at once, and
+    // a lane whose pixel has had its visit takes the next queued pixel - no wave waits for a slot, no lane idles while pixels are
+    // queued, and the frame needs no launch boundary to re-pack its lanes before the queue has run dry
+    bool refill = (trav == TRAVERSAL_WIDE || trav == TRAVERSAL_CERTIFIED) && g.config.segments_per_launch <= 0 && wave_slots > 0;
+    int refill_segments = kRestOfFrameSegments;
+    if (const char* e = getenv("PTMI_REFILL")) refill = refill && e[0] != '0';                      // A/B hooks of round 4
+    if (const char* e = getenv("PTMI_REFILL_SEGMENTS")) refill_segments = std::max(1, atoi(e));
 
     auto event = [&](size_t i) {
         while (g.event_pool.size() <= i) { hipEvent_t ev; PTMI_HIP(hipEventCreate(&ev)); g.event_pool.push_back(ev); }
@@ -942,7 +950,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         run[c].bound = r.chunk[c].n; run[c].finished = r.chunk[c].n == 0;
         for (int i = 0; i < kRing; i++) run[c].done[i] = event(n_ev++);
         PTMI_HIP(hipStreamWaitEvent(r.chunk[c].stream, ev_ready, 0));
-        if (publish) PTMI_HIP(hipMemsetAsync(r.chunk[c].d_count, 0, (kRing + 1) * sizeof(int), r.chunk[c].stream));   // once per frame
+        if (publish) PTMI_HIP(hipMemsetAsync(r.chunk[c].d_count, 0, (2 * kRing + 1) * sizeof(int), r.chunk[c].stream));   // once per frame
     }
     uint64_t launches = 0, visits = 0;
     const size_t first_pair_event = n_ev;
@@ -954,23 +962,30 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 const int slot_out = u.issued % kRing;
                 CountPublish pub;
                 if (publish) {
-                    pub.done_count = ch.d_count + kRing; pub.next_count = ch.d_count + (slot_out + 1) % kRing; pub.host_count = ch.d_hcount + slot_out;
+                    pub.done_count = ch.d_count + 2 * kRing; pub.next_count = ch.d_count + 2 * ((slot_out + 1) % kRing); pub.host_count = ch.d_hcount + slot_out;
                     __atomic_store_n(ch.h_count + slot_out, -1, __ATOMIC_RELEASE);      // "not there yet"
-                } else PTMI_HIP(hipMemsetAsync(ch.d_count + slot_out, 0, sizeof(int), ch.stream));
+                } else PTMI_HIP(hipMemsetAsync(ch.d_count + 2 * slot_out, 0, 2 * sizeof(int), ch.stream));     // output count and refill cursor
                 const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
                 long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
                 for (int k = 0; k < r.n_chunks; k++) active += run[k].finished ? 0 : run[k].bound;
                 const bool fits = wave_slots > 0 && (active + 63) / 64 * 100 <= wave_slots * fit_pct;
+                LaunchSchedule sched;
+                if (refill && active > 0) {
+                    // this chunk's share of the device's wave slots, by its share of the pixels still in flight (rounded down: the
+                    // chunks together must not ask for more waves than fit at once, or the surplus starts a whole launch late)
+                    sched.max_waves = std::max(4, (int)(wave_slots * (long long)u.bound / active) & ~3);
+                    sched.cursor = ch.d_count + 2 * slot_out + 1;
+                }
                 launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
-                              u.issued == 0 ? nullptr : ch.d_count + (u.issued - 1) % kRing, ch.d_queue[u.issued & 1], ch.d_count + slot_out,
-                              fits ? rest_segments : segments, want_stats ? r.d_stats : nullptr,
-                              phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream, pub);
+                              u.issued == 0 ? nullptr : ch.d_count + 2 * ((u.issued - 1) % kRing), ch.d_queue[u.issued & 1], ch.d_count + 2 * slot_out,
+                              refill ? refill_segments : fits ? rest_segments : segments, want_stats ? r.d_stats : nullptr,
+                              phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream, pub, sched);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
                 if (!publish) {
-                    PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
+                    PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + 2 * slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
                     PTMI_HIP(hipEventRecord(u.done[slot_out], ch.stream));
                 }
                 u.issued++;
