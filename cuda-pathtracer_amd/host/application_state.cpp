@@ -684,36 +684,26 @@ void RenderState::freeBuffers() {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d_frame_color = nullptr; frame_color_frames = 0; batch_frames = 1; batch_spp = 0;
     if (h_image) { (void)hipHostFree(h_image); h_image = nullptr; }
+    freeChunks();
+    d_state = PathState();
+    d_image = nullptr; d_radiance = nullptr; d_stats = nullptr;
+    n_local = 0;
+}
+
+void RenderState::freeChunks() {
     for (Chunk& c : chunk) {
         void* cp[] = {c.d_queue_init, c.d_queue[0], c.d_queue[1], c.d_count};
         for (void* p : cp) if (p) (void)hipFree(p);
         if (c.h_count) (void)hipHostFree(c.h_count);
         c.d_queue_init = c.d_queue[0] = c.d_queue[1] = c.d_count = nullptr; c.h_count = nullptr; c.d_hcount = nullptr; c.n = 0;
     }
-    d_state = PathState();
-    d_image = nullptr; d_radiance = nullptr; d_stats = nullptr;
-    n_local = 0;
+    n_chunks = 0;
 }
 
-void RenderState::allocateBuffers() {
-    freeBuffers();
-    tile.width = width; tile.height = height;
-    tile.local_rows = countLocalRows(height, tile.n_ranks, tile.rank, tile.row_block);
-    n_local = (size_t)tile.local_rows * (size_t)width;
-    tile.tile8 = (allow_tile8 && width % 8 == 0 && tile.local_rows % 8 == 0 && tile.row_block % 8 == 0) ? 1 : 0;
-    const size_t n = std::max<size_t>(n_local, 1);
-    d_state.A = (float4*)hipMallocSafe(n * sizeof(float4), "state.A");
-    d_state.B = (float4*)hipMallocSafe(n * sizeof(float4), "state.B");
-    d_state.C = (float4*)hipMallocSafe(n * sizeof(float4), "state.C");
-    d_state.D = (float4*)hipMallocSafe(n * sizeof(float4), "state.D");
-    d_state.E = (uint4*)hipMallocSafe(n * sizeof(uint4), "state.E");
-    d_state.F = (uint2*)hipMallocSafe(n * sizeof(uint2), "state.F");
-    d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
-    d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
-    d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
-    PTMI_HIP(hipHostMalloc((void**)&h_image, n * 3));                     // h_image = new unsigned char[img_size], application_state.h:99
-    // chunks: 256-slot blocks dealt round-robin, so a workgroup still reads 256 consecutive state records
-    n_chunks = want_chunks > 0 ? std::min(want_chunks, (int)kMaxChunks) : (n_local >= (size_t)(1 << 18) ? 2 : 1);
+// chunks: 256-slot blocks dealt round-robin, so a workgroup still reads 256 consecutive state records
+void RenderState::setupChunks(int n) {
+    freeChunks();
+    n_chunks = std::max(1, std::min(n, (int)kMaxChunks));
     std::vector<std::vector<int>> slots(n_chunks);
     for (size_t b = 0; b * kBlock < n_local; b++) {
         std::vector<int>& v = slots[b % n_chunks];
@@ -734,6 +724,26 @@ void RenderState::allocateBuffers() {
         PTMI_HIP(hipHostGetDevicePointer((void**)&ch.d_hcount, ch.h_count, 0));
         if (ch.n) PTMI_HIP(hipMemcpy(ch.d_queue_init, slots[c].data(), slots[c].size() * sizeof(int), hipMemcpyHostToDevice));
     }
+}
+
+void RenderState::allocateBuffers() {
+    freeBuffers();
+    tile.width = width; tile.height = height;
+    tile.local_rows = countLocalRows(height, tile.n_ranks, tile.rank, tile.row_block);
+    n_local = (size_t)tile.local_rows * (size_t)width;
+    tile.tile8 = (allow_tile8 && width % 8 == 0 && tile.local_rows % 8 == 0 && tile.row_block % 8 == 0) ? 1 : 0;
+    const size_t n = std::max<size_t>(n_local, 1);
+    d_state.A = (float4*)hipMallocSafe(n * sizeof(float4), "state.A");
+    d_state.B = (float4*)hipMallocSafe(n * sizeof(float4), "state.B");
+    d_state.C = (float4*)hipMallocSafe(n * sizeof(float4), "state.C");
+    d_state.D = (float4*)hipMallocSafe(n * sizeof(float4), "state.D");
+    d_state.E = (uint4*)hipMallocSafe(n * sizeof(uint4), "state.E");
+    d_state.F = (uint2*)hipMallocSafe(n * sizeof(uint2), "state.F");
+    d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
+    d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
+    d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
+    PTMI_HIP(hipHostMalloc((void**)&h_image, n * 3));                     // h_image = new unsigned char[img_size], application_state.h:99
+    setupChunks(want_chunks > 0 ? std::min(want_chunks, (int)kMaxChunks) : (n_local >= (size_t)(1 << 18) ? 2 : 1));
 
     // camera: image size + aspect, then updateCamera (application_state.h:106-109)
     h_camera.image_width = width; h_camera.image_height = height;
@@ -905,6 +915,13 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     int refill_segments = kRestOfFrameSegments;
     if (const char* e = getenv("PTMI_REFILL")) refill = refill && e[0] != '0';                      // A/B hooks of round 4
     if (const char* e = getenv("PTMI_REFILL_SEGMENTS")) refill_segments = std::max(1, atoi(e));
+    // With refill one launch keeps every wave slot busy by itself: a second chunk's kernel only competes with it (an eighth of the
+    // 1 M-triangle frame 1 661 -> 1 716 Msamples/s with one chunk, the whole frame 2 600 -> 2 795; three chunks: 1 628 / 2 501).  The
+    // automatic choice follows the walk; a forced count (config.streams) stays.
+    if (r.want_chunks == 0 && g.config.current_integrator == IntegratorType::PathTracing) {
+        const int want = refill ? 1 : (r.n_local >= (size_t)(1 << 18) ? 2 : 1);
+        if (want != r.n_chunks) { PTMI_HIP(hipStreamSynchronize(r.stream)); r.setupChunks(want); }
+    }
 
     auto event = [&](size_t i) {
         while (g.event_pool.size() <= i) { hipEvent_t ev; PTMI_HIP(hipEventCreate(&ev)); g.event_pool.push_back(ev); }

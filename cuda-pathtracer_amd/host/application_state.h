@@ -192,6 +192,8 @@ struct RenderState {
     void allocateBuffers();                          // application_state.h:91-123 (+ render_init)
     void updateResolution(int w, int h, const TileMap* tiling);   // application_state.h:125-129
     void freeBuffers();
+    void setupChunks(int n);                         // deals the local pixels to n queues (allocateBuffers; renderFrames when the walk's launch rule wants another count)
+    void freeChunks();
     ~RenderState() { freeBuffers(); }
 };
 

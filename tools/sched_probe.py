@@ -29,8 +29,9 @@ for share in shares:
     ref = None
     for v in variants:
         f = v.split(":"); budget, sparse, seg = f[0], f[1], int(f[2]) if len(f) > 2 else 0
+        streams = int(f[3]) if len(f) > 3 else 0
         os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"; os.environ["PTMI_REFILL_SEGMENTS"] = budget if int(budget) > 0 else "65536"
-        r.set_config(spp=spp, max_depth=depth, segments_per_launch=seg, collect_stats=False)
+        r.set_config(spp=spp, max_depth=depth, segments_per_launch=seg, collect_stats=False, streams=streams)
         setup(share)
         r.render_frame()
         rad = r.read_image(rgb8=False)[1]
@@ -41,5 +42,5 @@ for share in shares:
             setup(share)
             t0 = time.perf_counter(); s2 = r.render_frame(); ts.append(time.perf_counter() - t0)
         n = W * (H // share) * spp
-        print(f"{kind} 1/{share} spp {spp} budget {budget:>6} us sparse {sparse} seg {seg}: best {min(ts)*1e3:9.2f} ms = {n/min(ts)/1e6:8.1f} Msamples/s "
+        print(f"{kind} 1/{share} spp {spp} budget {budget:>6} us sparse {sparse} seg {seg} streams {streams}: best {min(ts)*1e3:9.2f} ms = {n/min(ts)/1e6:8.1f} Msamples/s "
               f"(all: {' '.join(f'{t*1e3:.1f}' for t in ts)}), {s2.bounce_launches} launches, kernel ms {s2.bounce_kernel_ms:.1f}; {nd} px differ from the first variant", flush=True)
