@@ -93,7 +93,7 @@ SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9             # max shader clock (MI355X_MICROARCH.md, chip-level parameters)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 # tools/gather_rate.hip on this GPU (profiles/r02_gather_rate.txt): dependent random fetches of 32-byte records, 28 active lanes
 # per wave, ~50 VALU instructions between fetches - 2.20e11 /s from a 20 MB table, 1.84e11 /s from a 120 MB one, the same at 3 and
 # at 8 waves per SIMD: the ceiling the large-scene walk runs against (its records: 20 MB of nodes, 36 MB of triangles, 16 MB of
@@ -120,6 +120,12 @@ CONFIGS = {
                         served_from="l2/mall/hbm", what="c5tile through the opt-in fast tree WITHOUT the certificate (ptmi_config.fast_tree: tolerance mode)"),
     "c5frame_fast": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", fast=True,
                          served_from="l2/mall/hbm", what="c5frame through the opt-in fast tree without the certificate"),
+    "c5tile_full": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=(8, 3, 8), kernel="ptmi_bounce_wide", counter_spp=64,
+                        profile_of="c5tile", served_from="l2/mall/hbm",
+                        what="BASELINE configs[4] at its stated 2048 spp, one GPU's share (rank 3 of 8), default = certified walk"),
+    "c5_full": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", counter_spp=64,
+                    profile_of="c5frame", served_from="l2/mall/hbm",
+                    what="BASELINE configs[4] at its stated size - 2048x2048, 2048 spp = 8.6 G samples - the WHOLE frame on one GPU, default = certified walk"),
     "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
                served_from="lds", what="BASELINE configs[3]"),
     "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide",
@@ -199,9 +205,11 @@ def cpu_baseline(cfg, width, height, target_seconds=12.0):
                       f"{st.samples / 1e6:.1f} Msamples in {st.seconds:.1f} s (oracle/ptmi_oracle.c, OpenMP over rows)"}
 
 
-def load_profile(name):
-    """profiles/<round>_pmc_<config>.json (tools/profile.sh + tools/pmc_summary.py), or (None, why)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{name}.json")
+def load_profile(name, scale_from=None, scale=1.0):
+    """profiles/<round>_pmc_<config>.json (tools/profile.sh + tools/pmc_summary.py), or (None, why).  scale_from: the profile
+    of that configuration - the same kernel on the same scene and tile at another spp - with its per-frame byte and instruction
+    counts multiplied by `scale` (= the ratio of the samples per frame); per-launch figures are dropped."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{scale_from or name}.json")
     if not os.path.exists(path):
         return None, "no committed profile"
     try:
@@ -213,6 +221,12 @@ def load_profile(name):
         return None, "profile_stale"
     prof["_matched"] = how
     prof["_path"] = os.path.relpath(path, ROOT)
+    if scale_from:
+        for k in ("hbm_bytes_per_frame", "fabric_read_bytes_per_frame", "hbm_write_bytes_per_frame", "valu_wave_insts_per_frame"):
+            if prof.get(k) is not None:
+                prof[k] = prof[k] * scale
+        prof["hbm_bytes_per_launch"] = None
+        prof["_path"] += f" x {scale:g} (samples per frame)"
     return prof, None
 
 
@@ -222,7 +236,10 @@ def roofline_block(name, cfg, m, exact_workload):
     launches = max(m["launches"], 1)
     steps = m["steps"]
     step_s = m["elapsed"] / steps
-    prof, why = load_profile(name) if exact_workload else (None, "workload differs from the profiled one")
+    if exact_workload and cfg.get("profile_of"):
+        prof, why = load_profile(name, cfg["profile_of"], cfg["spp"] / CONFIGS[cfg["profile_of"]]["spp"])
+    else:
+        prof, why = load_profile(name) if exact_workload else (None, "workload differs from the profiled one")
     # what this design sends to memory by construction: every queued pixel reads and writes its 88-byte state once per
     # launch (+ 4-byte queue entries in and out) - counted live by the library (ptmi_stats.path_visits)
     state_bytes_per_step = m["visits"] * (88 + 88 + 4 + 4) / steps
@@ -236,7 +253,8 @@ def roofline_block(name, cfg, m, exact_workload):
         if len(prof.get("bounce_kernels", [])) > 1:
             out["kernels_summed"] = prof["bounce_kernels"]
         hbm_bytes_per_step = prof["hbm_bytes_per_frame"]
-        out["traffic"] = round(prof["hbm_bytes_per_launch"], 1)          # 2 x FETCH_SIZE + WRITE_SIZE, per launch (guide: gfx950 rule)
+        # 2 x FETCH_SIZE + WRITE_SIZE, per launch (guide: gfx950 rule); a profile scaled from another spp has no per-launch figure
+        out["traffic"] = round(prof["hbm_bytes_per_launch"], 1) if prof["hbm_bytes_per_launch"] is not None else round(hbm_bytes_per_step / max(launches / steps, 1), 1)
         out["achieved_source"] = f"rocprofv3 PMC ({prof['_path']}, stamp matched by {prof['_matched']})"
         out["profile_stale"] = False
     else:
@@ -305,7 +323,9 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     # SURVEY 8(d)'s algorithmic figure, which is defined on the reference's node visits and primitive tests; (2) the walk that is
     # timed (certified / fast tree), for what it really fetches
     fast = bool(cfg.get("fast"))
-    r.set_config(spp=cfg["spp"], max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False, fast_tree=False)
+    # counter_spp: the two counter frames of a full-spp configuration of the 1 M-triangle scene are rendered at that many samples per
+    # pixel (per-ray and per-sample figures do not depend on the sample count; the reference's walk at 2048 spp would take 7 s)
+    r.set_config(spp=cfg.get("counter_spp", cfg["spp"]), max_depth=cfg["max_depth"], segments_per_launch=segments, collect_stats=True, download_image=False, fast_tree=False)
     auto = r.set_traversal(-1)
     own_walk = fast or (auto == r.CERTIFIED and cfg.get("traversal") is None)
     if auto == r.CERTIFIED:
@@ -317,7 +337,8 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
         r.set_config(fast_tree=fast)
         st_walk = r.render_frame()
     bytes_per_sample = algorithmic_bytes_per_sample(st_counts, r.scene_info()["n_quads"] > 0)
-    r.set_config(collect_stats=False)
+    r.set_config(collect_stats=False, spp=cfg["spp"])
+    counter_scale = cfg["spp"] / cfg.get("counter_spp", cfg["spp"])
     if warmup:
         run_steps(warmup, False, pipelined)
     kernel_ms = 0.0; launches = 0; visits = 0; frame_dev_s = 0.0
@@ -330,8 +351,8 @@ def measure(r, cfg, steps, warmup, run_steps, barrier, segments, reduce_max, pip
     n_local_px = len(r.local_rows()) * r.width
     return dict(elapsed=elapsed, steps=steps, kernel_ms=kernel_ms, launches=launches, visits=visits, frame_dev_s=frame_dev_s,
                 bytes_per_sample=bytes_per_sample, local_samples_per_step=float(n_local_px) * cfg["spp"],
-                streams=r.config.streams or (2 if n_local_px >= (1 << 18) else 1),
-                record_fetches_per_step=float(st_walk.node_visits - st_walk.top_node_visits + st_walk.prim_tests + st_walk.hits + (st_walk.hits if own_walk and not fast else 0)),
+                streams=r.config.streams or (1 if own_walk and not segments else 2 if n_local_px >= (1 << 18) else 1),      # (refill launches: one chunk)
+                record_fetches_per_step=counter_scale * float(st_walk.node_visits - st_walk.top_node_visits + st_walk.prim_tests + st_walk.hits + (st_walk.hits if own_walk and not fast else 0)),
                 top_node_visit_share=round(st_walk.top_node_visits / max(st_walk.node_visits, 1), 4),
                 counters=dict(rays_per_sample=round(st_counts.rays / st_counts.samples, 3),
                               nodes_per_ray=round(st_counts.node_visits / st_counts.rays, 2),
@@ -354,6 +375,7 @@ def main():
     ap.add_argument("--segments", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--streams", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--extra-budget", type=float, default=240.0, help="seconds the extra_configs may take in all; the ones left are recorded as skipped")
     ap.add_argument("--gather", choices=("rgb8", "radiance", "both"), default="rgb8", help="what the frame-end gather moves (N > 1)")
     ap.add_argument("--pipeline", action="store_true", help="render the K steps as ONE pipelined batch (ptmi_render_frames) instead of one "
                     "ptmi_render_frame call per step; without it the batch rate is still reported as value_pipelined_batch (N = 1)")
@@ -385,10 +407,10 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        # torch.distributed is the control plane only - the 128-byte unique id, and barriers / the max over ranks where the
+        # library has no communicator - and runs on gloo: the ONE RCCL communicator of the process is libptmi's own
+        # (ptmi_dist_init), which carries the frame gather, the barrier and the reduction of the timed region
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     name = args.config
     cfg = dict(CONFIGS[name])
@@ -455,14 +477,17 @@ def main():
     def barrier():
         if rccl:
             r.gather_wait()
-        if use_dist:
+            r.dist_barrier()                          # ptmi_dist_barrier: over the library's communicator, then a device-wide wait
+        elif use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def reduce_max(elapsed):
+        if rccl:
+            return r.dist_allreduce_max(elapsed)      # ptmi_dist_allreduce_max
         if not use_dist:
             return elapsed
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if shared else torch.device("cuda", device_index))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -525,13 +550,19 @@ def main():
     if world == 1 and not use_dist and name == "c2" and not args.no_extra and exact:
         extras = []
         loaded = None
-        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_packed", 6), ("c5tile_fast", 6), ("c5frame", 3), ("c5frame_packed", 2), ("c5frame_fast", 3)):
+        t_extras = time.perf_counter()
+        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_full", 2), ("c5tile_packed", 6), ("c5tile_fast", 6), ("c5frame", 3), ("c5_full", 1),
+                              ("c5frame_packed", 2), ("c5frame_fast", 3)):
+            t_x = time.perf_counter()
+            if t_x - t_extras > args.extra_budget:        # wall-clock guard: the line must come out whatever a box does
+                extras.append({"name": xname, "skipped": f"extra_configs had used {t_x - t_extras:.0f} s of their {args.extra_budget:.0f} s"})
+                continue
             xcfg = dict(CONFIGS[xname])
             if xcfg["scene"] != loaded:                   # the four 1 M-triangle workloads share one load
                 load_scene(r, xcfg["scene"]); loaded = xcfg["scene"]
             allocate(xcfg)
             vs_exact = None
-            if xcfg.get("fast") or (xcfg["scene"] == "tess1m" and not xcfg.get("traversal")):
+            if (xcfg.get("fast") or (xcfg["scene"] == "tess1m" and not xcfg.get("traversal"))) and xname != "c5_full":      # (c5_full: 7 s through the reference's tree; tests/test_gpu_fullsize.py covers rows of it)
                 # what the other tree changes in the result, measured on this very workload: one frame through the reference's own tree
                 # (packed layout) and one through the timed walk (certified: must be 0 pixels; fast tree: reported) from the same
                 # RNG state (update_resolution re-seeds), compared pixel by pixel
@@ -548,15 +579,20 @@ def main():
                             "max_abs": float(np.abs(frames[0].astype(np.float64) - frames[1]).max()),
                             "rmse": float(np.sqrt(np.mean((frames[0].astype(np.float64) - frames[1]) ** 2))),
                             "what": "float radiance of one frame of this workload, the timed walk vs the reference's own tree (packed layout), same RNG state "
-                                    "(certified walk: identical by construction; fast tree: bar RMSE < 1e-4)"}
+                                    "(certified walk: every hit is proven to be the one the reference's walk returns, or walked by that walk - "
+                                    "identical whenever the proof's stated precondition holds, DESIGN.md 4.9 - and measured here; fast tree: bar RMSE < 1e-4)"}
                 allocate(xcfg)
-            xm = measure(r, xcfg, xsteps, 1, run_steps, barrier, 0, reduce_max, pipelined)
+            xwarm = 0 if xname == "c5_full" else 1     # (its two counter frames have warmed everything a 3 s frame can warm)
+            xm = measure(r, xcfg, xsteps, xwarm, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps
             tiled = f", rank {xcfg['tiling'][1]} of {xcfg['tiling'][0]}" if xcfg["tiling"] else ""
             extras.append({"name": xname, "workload": f"{xcfg['scene']} {xcfg['width']}x{xcfg['height']}, {xcfg['spp']} spp, max_depth {xcfg['max_depth']}{tiled} ({xcfg['what']})",
-                           "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "steps": xsteps, "warmup": 1,
+                           "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "steps": xsteps, "warmup": xwarm,
                            "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"],
                            "roofline": roofline_block(xname, xcfg, xm, True)})
+            if xcfg.get("counter_spp"):
+                extras[-1]["counters_from"] = f"counter frames at {xcfg['counter_spp']} spp (per-ray / per-sample figures do not depend on the sample count)"
+            extras[-1]["wall_s"] = round(time.perf_counter() - t_x, 1)
             if vs_exact:
                 extras[-1]["fast_tree_vs_exact" if xcfg.get("fast") else "certified_vs_reference_tree"] = vs_exact
         r.set_config(fast_tree=False)
@@ -569,7 +605,15 @@ def main():
     if world > 1 and name == "c2" and not args.no_extra and not args.side and not args.spp:
         extras = []
         loaded = cfg["scene"]
+        t_extras = time.perf_counter()
         for xname, xsteps in (("c4", 2), ("c5strong", 3), ("c5strong_packed", 3), ("c5strong_fast", 3), ("c5", 1)):
+            t_x = time.perf_counter()
+            # wall-clock guard, decided by rank 0 for everyone (ranks must stay in step)
+            over = reduce_max(1.0 if t_x - t_extras > args.extra_budget else 0.0) > 0.0
+            if over:
+                if rank == 0:
+                    extras.append({"name": xname, "skipped": f"extra_configs had used their {args.extra_budget:.0f} s"})
+                continue
             try:
                 xcfg = dict(CONFIGS[xname])
                 if args.rehearse_gloo or args.rehearse_shared_gpu:     # rehearsal on one shared GPU: same control flow, small frames
@@ -585,7 +629,7 @@ def main():
                     extras.append({"name": xname, "scaling": "strong", "workload": f"{xcfg['scene']} {xcfg['width']}x{xcfg['height']}, {xcfg['spp']} spp, max_depth "
                                    f"{xcfg['max_depth']}, rows tiled over {world} GPUs in interleaved 8-row blocks + 1 RCCL gather ({args.gather}) per frame ({xcfg['what']})",
                                    "value": round(xsamples / xm["elapsed"] / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": xsteps, "warmup": 1,
-                                   "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), **xm["counters"]})
+                                   "ms_per_step": round(xm["elapsed"] / xsteps * 1e3, 3), "wall_s": round(time.perf_counter() - t_x, 1), **xm["counters"]})
             except Exception as e:                       # noqa: BLE001 - recorded, the run goes on
                 if rank == 0:
                     extras.append({"name": xname, "error": f"{type(e).__name__}: {e}"})
@@ -597,6 +641,7 @@ def main():
     if rank == 0:
         if rccl:
             out["rccl_ranks"] = r.dist_comm_count()       # what RCCL itself reports for the communicator the gathers ran on (ncclCommCount)
+            assert out["rccl_ranks"] == world, f"RCCL sees {out['rccl_ranks']} ranks, the launcher started {world}"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, cfg["width"], cfg["height"])
         print(json.dumps(out), flush=True)

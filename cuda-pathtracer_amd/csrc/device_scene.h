@@ -72,7 +72,7 @@ struct DeviceScene {
     const uint4* wanc = nullptr;       // per reference leaf: its ancestors' pre-order node indices (leaf included), 4 per chunk, 0xffffffff pads
     const float4* wqprims = nullptr;   // scenes with quads: 64-byte records (v0 | type, e1, e2, e3) in the fast tree's order instead of wprims
     const float4* wcert = nullptr;     // per fast-order triangle: (leaf box min, bits(first chunk << 5 | chunks of the leaf's list)) (leaf box max, 0)
-    float w_big = 0.0f;                // the scene's largest |coordinate|
+    float w_big = 0.0f;                // the scene's scale (host/wide_bvh.h: WideBVH::scale); informational since the certificate takes eps from each box
     int w_cert_debug = 0;              // test hook of the solver's certified walk: 1 every blocked ray takes the ancestor chain, 2 the reference's walk
     const int* wfast_of_ref = nullptr; // reference leaf-order slot -> fast order
     float w_guard = 0.0f;              // the boxes are padded for ray origins with |coordinate| <= w_guard; others take the reference's walk
@@ -175,6 +175,7 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
                     const float4* color_src = nullptr);
 
 size_t bounce_lds_bytes(const DeviceScene& sc);
+size_t bounce_lds_bytes_wide(const DeviceScene& sc);      // dynamic LDS of the 8-wide walks for this scene (top of the tree + stacks)
 
 // ---- radiosity pre-pass (radiosity.hip) ----------------------------------------------------------------
 // Load-order geometry the form-factor kernels sample (the traversal keeps using the leaf-order prims above):

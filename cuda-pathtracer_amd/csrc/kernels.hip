@@ -1034,9 +1034,13 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     // overflow) or a point within eps of a face goes to the chain of exact slab tests instead.
                     const float4 lo = a.sc.wcert[2 * (size_t)slot_hit], hi = a.sc.wcert[2 * (size_t)slot_hit + 1];
                     const f3 q = p.o + closest_t * p.d;
-                    const float big = a.sc.w_big;
-                    const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + big), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + big),
-                                ez = 9.5367431640625e-7f * (fabsf(p.o.z) + big);
+                    // eps from THIS box's own coordinates M_a = max(|lo_a|, |hi_a|) (round 3 took the scene's largest coordinate: one
+                    // far-away primitive then sent every hit of the scene to the chain).  A point inside the box has |Q_a| <= M_a and
+                    // |t* d_a| <= |o_a| + M_a, so the bounds above sum to <= 11 * 2^-24 (|o_a| + M_a) < eps; and the margin carries to
+                    // every ancestor: a face of an ancestor at X lies |X - F| beyond the leaf's face F, its own arithmetic error
+                    // 2^-22 (|o_a| + |X|) <= 2^-22 (|o_a| + |F| + |X - F|) stays below eps + |X - F|
+                    const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + fmaxf(fabsf(lo.x), fabsf(hi.x))), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                                ez = 9.5367431640625e-7f * (fabsf(p.o.z) + fmaxf(fabsf(lo.z), fabsf(hi.z)));
                     const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
                     const bool finite_slopes = fabsf(p.d.x) >= 8.673617379884035e-19f && fabsf(p.d.y) >= 8.673617379884035e-19f && fabsf(p.d.z) >= 8.673617379884035e-19f;
                     if (inside && finite_slopes) phase = PH_SHADE;
@@ -1059,13 +1063,12 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     // from the leaf upwards: a box that holds Q with the margin settles all boxes above it (nested) - usually the
                     // leaf's parent or grandparent; below it every box has to pass the reference's own slab test
                     const f3 q = p.o + closest_t * p.d;
-                    const float big = a.sc.w_big;
-                    const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + big), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + big),
-                                ez = 9.5367431640625e-7f * (fabsf(p.o.z) + big);
                     const float slopes = min3_raw(fabsf(p.d.x), fabsf(p.d.y), fabsf(p.d.z)) - 8.673617379884035e-19f;
                     bool proven = false, failed = false;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
+                        const float ex = 9.5367431640625e-7f * (fabsf(p.o.x) + fmaxf(fabsf(n0[c].x), fabsf(n1[c].x))), ey = 9.5367431640625e-7f * (fabsf(p.o.y) + fmaxf(fabsf(n0[c].y), fabsf(n1[c].y))),
+                                    ez = 9.5367431640625e-7f * (fabsf(p.o.z) + fmaxf(fabsf(n0[c].z), fabsf(n1[c].z)));      // this box's own eps (see the one-fetch step)
                         const float mx = min3_raw(q.x - n0[c].x - ex, n1[c].x - q.x - ex, slopes);
                         const float my = min3_raw(q.y - n0[c].y - ey, n1[c].y - q.y - ey, q.z - n0[c].z - ez);
                         const bool holds = min3_raw(mx, my, n1[c].z - q.z - ez) >= 0.0f;
@@ -1178,8 +1181,9 @@ extern "C" int ptmi_trace_read(unsigned long long* out) {       // reads and cle
 }
 #endif
 
+size_t bounce_lds_bytes_wide(const DeviceScene& sc) { return (size_t)sc.w_top * kWideNodeDwords * 4 + (size_t)sc.w_depth * kBlock * sizeof(uint2); }
 size_t bounce_lds_bytes(const DeviceScene& sc) {
-    if (sc.traversal == TRAVERSAL_WIDE || sc.traversal == TRAVERSAL_CERTIFIED) return (size_t)sc.w_top * kWideNodeDwords * 4 + (size_t)sc.w_depth * kBlock * sizeof(uint2);
+    if (sc.traversal == TRAVERSAL_WIDE || sc.traversal == TRAVERSAL_CERTIFIED) return bounce_lds_bytes_wide(sc);
     size_t b = 0;
     const bool geom = sc.lds_resident || sc.traversal == TRAVERSAL_SWEEP;
     if (geom) b += (size_t)(2 * sc.n_nodes + (sc.prim_stride + 3) * sc.n_prims) * sizeof(float4);

@@ -180,10 +180,11 @@ __device__ __forceinline__ bool visibility_blocked(const DeviceScene& sc, f3 o, 
 //     anyhit_box over the leaf's ancestor list (wanc), leaf first, up to the first box that holds Q with the margin; a box of
 //     that list failing: the reference's own walk for this ray.
 template <bool CERT, bool QUADS = false>
-__device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 lo, float4 hi, float t, f3 o, f3 d, float max_dist, int slot_a, int slot_b, unsigned int& chain) {
+__device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 lo, float4 hi, float t, f3 o, f3 d, float max_dist, int slot_a, int slot_b, unsigned long long& chain) {
     const f3 q = o + t * d;
-    const float big = sc.w_big;
-    const float ex = 9.5367431640625e-7f * (fabsf(o.x) + big), ey = 9.5367431640625e-7f * (fabsf(o.y) + big), ez = 9.5367431640625e-7f * (fabsf(o.z) + big);
+    // eps from the box's own coordinates (kernels.hip, VERIFY: the same bound and the same argument for the ancestors)
+    const float ex = 9.5367431640625e-7f * (fabsf(o.x) + fmaxf(fabsf(lo.x), fabsf(hi.x))), ey = 9.5367431640625e-7f * (fabsf(o.y) + fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                ez = 9.5367431640625e-7f * (fabsf(o.z) + fmaxf(fabsf(lo.z), fabsf(hi.z)));
     const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
     const bool slopes = fabsf(d.x) >= 1.4901161193847656e-8f && fabsf(d.y) >= 1.4901161193847656e-8f && fabsf(d.z) >= 1.4901161193847656e-8f;   // 2^-26 > 1e-8
     if (inside && slopes && sc.w_cert_debug == 0) return true;
@@ -200,19 +201,21 @@ __device__ __forceinline__ bool certified_blocked(const DeviceScene& sc, float4 
         for (int c = 0; c < 4; c++) {
             const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];          // padding repeats the root
             const float4 n0 = sc.nodes[2 * (size_t)j], n1 = sc.nodes[2 * (size_t)j + 1];
-            const bool holds = slopes && q.x - n0.x >= ex && n1.x - q.x >= ex && q.y - n0.y >= ey && n1.y - q.y >= ey && q.z - n0.z >= ez && n1.z - q.z >= ez;
+            const float nx = 9.5367431640625e-7f * (fabsf(o.x) + fmaxf(fabsf(n0.x), fabsf(n1.x))), ny = 9.5367431640625e-7f * (fabsf(o.y) + fmaxf(fabsf(n0.y), fabsf(n1.y))),
+                        nz = 9.5367431640625e-7f * (fabsf(o.z) + fmaxf(fabsf(n0.z), fabsf(n1.z)));
+            const bool holds = slopes && q.x - n0.x >= nx && n1.x - q.x >= nx && q.y - n0.y >= ny && n1.y - q.y >= ny && q.z - n0.z >= nz && n1.z - q.z >= nz;
             ok = ok && (proven || holds || anyhit_box(n0, n1, o, inv, max_dist));
             proven = proven || holds;
         }
     }
     if (ok && sc.w_cert_debug < 2) return true;
-    chain += 0x10000u;
+    chain += 1ull << 32;
     return visibility_blocked<QUADS, false>(sc, o, d, max_dist, slot_a, slot_b);
 }
 
 template <bool CERT, bool QUADS>
 __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float max_dist, int load_a, int load_b,
-                                                        int slot_a, int slot_b, unsigned int& chain) {
+                                                        int slot_a, int slot_b, unsigned long long& chain) {
     const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
     const uint32_t octinv = wide_octinv(inv);
     int sp = 0;
@@ -341,7 +344,7 @@ __device__ __forceinline__ void pair_rng_init(uint32_t* M, const uint32_t* __res
 // 13 - 18 registers do not have to live through the visibility walk, where the kernel is short of them (7 waves per SIMD).
 template <bool HAS_QUADS, bool DEEP, bool RAD0, int WIDE>
 __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, int i, const Geom& gi, const float4* __restrict__ geo, int j, int slot_i, int slot_j,
-                                         int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays, unsigned int& chain) {
+                                         int actual_samples, Rng& rng, f3 radiosity_j, unsigned int* counts, float* radg, unsigned int& rays, unsigned long long& chain) {
     float visibility_sum = 0.0f, cos_i_sum = 0.0f, cos_j_sum = 0.0f, dist_sum = 0.0f;
     int valid_samples = 0;
     for (int s = 0; s < actual_samples; ++s) {
@@ -391,7 +394,7 @@ __device__ __forceinline__ float mc_pair(const DeviceScene& sc, uint2* wstack, i
 // calculate_form_factors_kernel (form_factors.h:368-415) after its culling tests
 template <bool HAS_QUADS, bool DEEP, int WIDE>
 __device__ __forceinline__ float p2p_pair(const DeviceScene& sc, uint2* wstack, int i, int j, const Geom& gi, const Geom& gj, int slot_i, int slot_j, unsigned int& rays,
-                                          unsigned int& chain) {
+                                          unsigned long long& chain) {
     const f3 vec_ij = gj.centroid - gi.centroid;
     const float r = length(vec_ij);
     const f3 dir_ij = div_scalar(vec_ij, r);
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_fo
     if (RAD0) { radg[3 * tid] = 0.0f; radg[3 * tid + 1] = 0.0f; radg[3 * tid + 2] = 0.0f; }
     if (tid == 0) { q_n = 0; rays_wg = 0u; }
     __syncthreads();
-    unsigned int rays = 0u, chain = 0u;           // chain: certified walk - rays that took the ancestor chain (low half) / the reference's walk (high half)
+    unsigned int rays = 0u;
+    unsigned long long chain = 0ull;              // certified walk: rays that took the ancestor chain (low word) / the reference's walk (high word)
 
     for (int base = 0; base < n; base += kBlock) {
         const int j = base + tid;
@@ -504,7 +508,11 @@ __global__ __launch_bounds__(kBlock, WIDE ? PTMI_FF_WIDE_WAVES : 7) void ptmi_fo
     rb.rad_grid[(size_t)i * kGridSize + tid] = RAD0 ? make_float4(radg[3 * tid], radg[3 * tid + 1], radg[3 * tid + 2], 0.0f)
                                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (tid == 0 && rb.rays) atomicAdd(rb.rays, (unsigned long long)rays_wg);
-    if (WIDE == 2 && chain && rb.rays) { atomicAdd(rb.rays + 1, (unsigned long long)(chain & 0xffffu)); atomicAdd(rb.rays + 2, (unsigned long long)(chain >> 16)); }
+    if (WIDE == 2 && rb.rays) {                    // one pair of atomics per wave (the two 32-bit words cannot carry into each other: a lane's rays stay far below 2^32)
+        unsigned long long c = chain;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if ((threadIdx.x & 63) == 0 && c) { atomicAdd(rb.rays + 1, c & 0xffffffffull); atomicAdd(rb.rays + 2, c >> 32); }
+    }
 }
 
 // radiosity_iteration_kernel (form_factors.h:441-465): one thread per receiver, ascending j - the float sum is a

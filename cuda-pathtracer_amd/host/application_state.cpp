@@ -90,6 +90,7 @@ void SceneState::cleanup() {
     if (d_radiosity) (void)hipFree(d_radiosity);
     freePacked();
     freeFast();
+    fast_declined = false;
     d_nodes = d_prims = d_mats = nullptr; d_precomputed_cdfs = nullptr; d_radiosity = nullptr;
     h_precomputed_cdfs.clear(); h_radiosity_grids.clear(); h_count_grids.clear(); h_filtered_formfactor.clear(); h_filtered_radiosity.clear();
     d_scene = DeviceScene();
@@ -205,7 +206,8 @@ void SceneState::upload() {
     // the reference's tree (128 ... 1 M triangles, planar scenes included; 1 M triangles: +1.3 s of loading, +145 MB)
     if (n > sweep_max_prims && bvh_depth <= 62 && certified_default) {
         try { buildFast(); }
-        catch (const ArgError&) { freeFast(); }        // a scene the builder declines (tree deeper than 48): the reference's tree is walked
+        catch (const ArgError&) { freeFast(); }        // a scene the builder declines (tree too deep for the walk's LDS stack, coordinates of 1e9): the reference's tree is walked
+        catch (const HipError&) { freeFast(); (void)hipGetLastError(); }      // no memory for the second tree: the scene still loads
     }
     chooseTraversal();
 }
@@ -336,9 +338,13 @@ void SceneState::freeFast() {
 void SceneState::buildFast() {
     freeFast();
     if (!d_nodes) throw ArgError("fast tree: no scene loaded");
+    fast_declined = true;                              // until the build has gone through
     try { buildWideBVH(h_primitives, wide_params, h_wide); }
-    catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
-    if (h_wide.depth > 48) { h_wide.clear(); throw ArgError("fast tree: deeper than 48 levels"); }
+    catch (const std::exception& e) { h_wide.clear(); throw ArgError(e.what()); }      // every builder failure: the callers' fallback catches ArgError
+    // The walk's stack is (levels - 1) x 256 lanes x 8 bytes of the workgroup's LDS, next to the tree's top and - in the radiosity
+    // pre-pass - 7 KB of static arrays; a launch may ask for 64 KB.  24 levels = 46 KB leaves room for both (an 8-wide tree of a
+    // million triangles has 9 levels); a deeper tree is declined and the scene walks the reference's tree.
+    if (h_wide.depth > kWideMaxLevels) { h_wide.clear(); throw ArgError("fast tree: deeper than " + std::to_string(kWideMaxLevels) + " levels"); }
     const int n = (int)h_primitives.size();
     auto bits = [](int i) { float f; std::memcpy(&f, &i, 4); return f; };
     std::vector<int> ref_slot_of_load((size_t)n), ref_slot((size_t)n);
@@ -433,7 +439,9 @@ void SceneState::buildFast() {
     d_scene.wnodes = d_wnodes; d_scene.w_nodes = h_wide.n_nodes; d_scene.w_top = top; d_scene.w_depth = stack_entries;
     d_scene.wqprims = d_wqprims;
     d_scene.wprims = d_wprims; d_scene.wmats = d_wmats; d_scene.wmtab = d_wmtab; d_scene.wload_index = d_wload_index; d_scene.wref_slot = d_wref_slot;
-    d_scene.wanc = d_wanc; d_scene.wcert = d_wcert; d_scene.wfast_of_ref = d_wfast_of_ref; d_scene.w_guard = h_wide.origin_guard; d_scene.w_big = 0.25f * h_wide.origin_guard;
+    d_scene.wanc = d_wanc; d_scene.wcert = d_wcert; d_scene.wfast_of_ref = d_wfast_of_ref; d_scene.w_guard = h_wide.origin_guard; d_scene.w_big = h_wide.scale;
+    if (bounce_lds_bytes_wide(d_scene) > 56 * 1024) { freeFast(); throw ArgError("fast tree: the walk's LDS does not fit a workgroup"); }
+    fast_declined = false;
 }
 
 void SceneState::setRadiosity(const float* rgb) {
@@ -506,7 +514,14 @@ void RadiosityState::runSolver(SceneState& scene, const uint32_t* d_jump, bool e
         if (can && fast_tree) walk = 1;
         else if (can && (force_walk >= 2 || (force_walk < 0 && scene.certified_default && n >= cert_min_prims))) walk = 2;
         if (walk) {
-            if (!scene.fastReady()) scene.buildFast();
+            // the automatic choice falls back to the reference's walk for a scene the builder declines (and does not ask again);
+            // a walk the caller asked for by name (fast_tree, force_walk) reports the failure
+            const bool automatic = !fast_tree && force_walk < 0;
+            if (!scene.fastReady() && !(automatic && scene.fast_declined)) {
+                try { scene.buildFast(); }
+                catch (const ArgError&) { if (!automatic) throw; }
+            }
+            if (!scene.fastReady()) walk = 0;
             if (walk == 2 && !(scene.d_scene.wcert && scene.d_scene.wanc)) walk = 0;
         }
         d.fast_tree = walk;

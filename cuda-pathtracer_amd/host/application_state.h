@@ -72,7 +72,9 @@ struct SceneState {
     // opt-in fast tree for TRAVERSAL_WIDE (csrc/wide_bvh.h), built at the first frame that asks for it (AppConfig::fast_tree)
     WideBVH h_wide;
     WideBVHParams wide_params;
-    bool certified_default = true;                   // scenes that get the packed layout and have no quads walk CERTIFIED by default
+    bool certified_default = true;                   // scenes above the sweep's 64 primitives (triangles and quads) walk CERTIFIED by default
+    bool fast_declined = false;                      // the last buildFast() failed: the automatic choices do not ask again for this scene
+    static constexpr int kWideMaxLevels = 24;        // deepest 8-wide tree the walk's LDS stack takes (buildFast)
     int wide_top_nodes = 80;                         // whole levels of the fast tree kept in LDS while they fit this many nodes (128 B each)
     uint4* d_wnodes = nullptr;
     float* d_wprims = nullptr;
@@ -82,7 +84,7 @@ struct SceneState {
     float4* d_wcert = nullptr;
     float4* d_wqprims = nullptr;
     int* d_wfast_of_ref = nullptr;
-    void buildFast();                                // host build + upload; throws ArgError for scenes with quads
+    void buildFast();                                // host build + upload (triangles and quads); throws ArgError when the builder or the walk's LDS budget declines the scene
     void freeFast();
     bool fastReady() const { return d_wnodes != nullptr; }
     DeviceScene d_scene;

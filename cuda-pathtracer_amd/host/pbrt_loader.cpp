@@ -13,7 +13,7 @@
 // restated too - header grammar, ASCII and both binary byte orders, every scalar type with rply's range checks, lists -
 // for what the import uses: vertex x/y/z (+ nx/ny/nz), the face list vertex_indices / vertex_index, triangles only.
 //
-// Not restated (the load fails with a message naming the construct): "spectrum" parameters read from .spd files, shape
+// Not restated (the load fails with a message naming the construct): shape
 // types the reference importer crashes on (it dereferences the null shape of every type but trianglemesh / plymesh / curve /
 // sphere / disk).  Rotate calls the host libm's sinf / cosf exactly as the library does (the numerics contract's sincos differs
 // from glibc's in the last bit on 2.6 % of angles, which would show in every rotated vertex).
@@ -367,8 +367,16 @@ struct Parser {
             std::string v = next().text;
             while (v != "]") { add(v); v = next().text; }
         } else {
-            if (type == "spectrum") throw PbrtError("spectrum parameters read from .spd files are not supported");
-            add(value);
+            if (type == "spectrum") {
+                // a measured spectrum: the named file (relative to the scene's directory unless absolute) is tokenised by the same
+                // lexer and EVERY token joins the parameter as a float (Parser.inl:208-224) - (wavelength, value) pairs for the
+                // material to take with getParamPairNf (Materials.cpp:164-183); a file that is not there, or a token that is not
+                // a number, fails the load as it does in the library
+                std::string file = value;
+                if (file.empty() || file[0] != '/') file = rootNamePath + "/" + file;
+                Lexer spd(file);
+                for (Token x = spd.next(); x; x = spd.next()) add(x.text);
+            } else add(value);
         }
         into.param[comp[1]] = p;
         return true;

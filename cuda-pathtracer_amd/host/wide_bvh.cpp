@@ -125,19 +125,39 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
     auto n_verts = [](const Primitive& p) { return p.type == PRIM_QUAD ? 4 : 3; };
 
     // triangle boxes, padded.  The node test computes a plane distance as fma(q, 2^e / d, (p - o) / d): its error is a few
-    // 2^-24 of |p - o| + the node's extent, i.e. of |o| + the scene's largest coordinate `big`.  For origins with |coordinate|
-    // <= 4 big (the certified walk sends any other ray through the reference's walk) that is below 5 big * 4 * 2^-24 =
-    // 2^-19.7 big; every box is widened by 2^-16 big (cbox: 9e-5, a two-hundredth of the 1 M-triangle scene's cell) plus the
-    // reference's own 1e-6 (bvh.h:108-114): an order of magnitude of slack, so that no triangle the ray hits is ever culled
+    // 2^-24 of |p - o| + the node's extent, i.e. of |o| + the largest coordinate X of the NODE the child sits in.  With S the
+    // scale of the scene - its largest coordinate, unless a few far-away primitives stick out (below) - origins are good up
+    // to |coordinate| <= 4 S (the certified walk sends any other ray through the reference's walk), so a node with X <= S is
+    // off by less than 5 S * 4 * 2^-24 = 2^-19.7 S; every primitive's box is widened by 2^-16 max(S, its own largest
+    // coordinate) (cbox: 9e-5, a two-hundredth of the 1 M-triangle scene's cell) plus the reference's own 1e-6
+    // (bvh.h:108-114), and a child box stored in a node that reaches beyond S by a further 2^-16 (X - S): an order of magnitude
+    // of slack, so that no triangle the ray hits is ever culled.
+    // S: round 3 took the largest coordinate of the scene, so ONE primitive a million units away widened every box of a
+    // ten-unit scene by 15 units and the 8-wide tree decided nothing any more (the frames stayed right: everything was tested).
+    // Now S = min(largest coordinate, 8 x the 99th percentile of the primitives' largest coordinates): the same value for
+    // every scene whose primitives lie within 8 x the bulk's range, and the bulk's scale when a few lie far outside.
     std::vector<Box> pbox((size_t)n);
     std::vector<std::array<float, 3>> pcen((size_t)n);
+    std::vector<float> pmag((size_t)n, 0.0f);
     float big = 0.0f;
-    for (const Primitive& p : prims) for (int k = 0; k < n_verts(p); k++) big = std::max(big, std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
-    if (!(big < 1.0e9f)) throw std::invalid_argument("fast tree: coordinates must stay below 1e9");
-    const float pad = big * (1.0f / 65536.0f) + 1e-6f;
-    out.origin_guard = 4.0f * big;
     for (int i = 0; i < n; i++) {
         const Primitive& p = prims[i];
+        for (int k = 0; k < n_verts(p); k++) pmag[i] = std::max(pmag[i], std::max(std::fabs(p.v[k].x), std::max(std::fabs(p.v[k].y), std::fabs(p.v[k].z))));
+        big = std::max(big, pmag[i]);
+    }
+    if (!(big < 1.0e9f)) throw std::invalid_argument("fast tree: coordinates must stay below 1e9");
+    float scale = big;
+    {
+        std::vector<float> sorted(pmag);
+        const size_t k99 = (size_t)(0.99 * (double)(n - 1));
+        std::nth_element(sorted.begin(), sorted.begin() + (std::ptrdiff_t)k99, sorted.end());
+        if (sorted[k99] > 0.0f) scale = std::min(big, 8.0f * sorted[k99]);
+    }
+    out.origin_guard = 4.0f * scale;
+    out.scale = scale;
+    for (int i = 0; i < n; i++) {
+        const Primitive& p = prims[i];
+        const float pad = std::max(scale, pmag[i]) * (1.0f / 65536.0f) + 1e-6f;
         Box b;
         for (int k = 0; k < n_verts(p); k++) { const float v[3] = {p.v[k].x, p.v[k].y, p.v[k].z}; b.grow(v); }
         for (int a = 0; a < 3; a++) { pcen[i][a] = 0.5f * (b.lo[a] + b.hi[a]); b.lo[a] -= pad; b.hi[a] += pad; }
@@ -213,8 +233,20 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
             }
         }
         // ---- slots: child c goes to the slot whose corner direction its centre lies towards (greedy on the best pairs) ----
-        Box nb;
-        for (int k = 0; k < ns; k++) nb.grow(N[set[k]].box);
+        // the children's boxes as this node stores them: widened once more where the node reaches beyond the scene's scale
+        Box cbox[8], nb;
+        {
+            Box raw;
+            for (int k = 0; k < ns; k++) raw.grow(N[set[k]].box);
+            float reach = 0.0f;
+            for (int a = 0; a < 3; a++) reach = std::max(reach, std::max(std::fabs(raw.lo[a]), std::fabs(raw.hi[a])));
+            const float extra = reach > scale ? (reach - scale) * (1.0f / 65536.0f) : 0.0f;
+            for (int k = 0; k < ns; k++) {
+                cbox[k] = N[set[k]].box;
+                for (int a = 0; a < 3; a++) { cbox[k].lo[a] -= extra; cbox[k].hi[a] += extra; }
+                nb.grow(cbox[k]);
+            }
+        }
         int slot_of[8]; bool slot_used[8] = {}, placed[8] = {};
         for (int round = 0; round < ns; round++) {
             double bestc = -std::numeric_limits<double>::infinity(); int bc = -1, bs = -1;
@@ -233,9 +265,9 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
             }
             placed[bc] = true; slot_used[bs] = true; slot_of[bc] = bs;
         }
-        int child_in_slot[8]; bool leaf_in_slot[8];
-        for (int s = 0; s < 8; s++) { child_in_slot[s] = -1; leaf_in_slot[s] = false; }
-        for (int k = 0; k < ns; k++) { child_in_slot[slot_of[k]] = set[k]; leaf_in_slot[slot_of[k]] = set_leaf[k]; }
+        int child_in_slot[8], k_in_slot[8]; bool leaf_in_slot[8];
+        for (int s = 0; s < 8; s++) { child_in_slot[s] = -1; k_in_slot[s] = -1; leaf_in_slot[s] = false; }
+        for (int k = 0; k < ns; k++) { child_in_slot[slot_of[k]] = set[k]; k_in_slot[slot_of[k]] = k; leaf_in_slot[slot_of[k]] = set_leaf[k]; }
 
         // ---- record ----
         const size_t base = nodes.size();
@@ -258,7 +290,7 @@ void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm_
         for (int s = 0; s < 8; s++) {
             const int c = child_in_slot[s];
             if (c < 0) continue;
-            const Box& cbx = N[c].box;
+            const Box& cbx = cbox[k_in_slot[s]];
             for (int a = 0; a < 3; a++) {
                 // outward rounding, checked in the arithmetic the kernel's planes stand for: p + q * 2^e as exact reals
                 int lo = (int)std::floor(((double)cbx.lo[a] - (double)nb.lo[a]) / step[a]);

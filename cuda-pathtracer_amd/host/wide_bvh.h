@@ -21,7 +21,8 @@ struct WideBVH {
     std::vector<int> tri_load_index;    // fast order -> load-order primitive index
     std::vector<int> level_start;       // first node index of every level (+ a final entry = n_nodes)
     int n_nodes = 0, depth = 0;         // depth: levels of wide nodes (root = 1) = most entries the walk's stack ever holds + 1
-    float origin_guard = 0.0f;          // the triangle boxes are padded for ray origins with |coordinate| <= this (4 x the scene's largest)
+    float origin_guard = 0.0f;          // the boxes are padded for ray origins with |coordinate| <= this (4 x scale)
+    float scale = 0.0f;                 // the scene's largest coordinate, or 8 x the 99th percentile of its primitives' when a few lie far outside
     double sah = 0.0;                   // for inspection: sum of (child area / root area) over all children of all nodes
     int binary_nodes = 0, binary_leaves = 0;
     int fill_hist[9] = {}, leaf_hist[4] = {};   // nodes by number of children; leaf children by number of triangles
@@ -29,7 +30,8 @@ struct WideBVH {
     void clear() { *this = WideBVH(); }
 };
 
-// Triangle scenes only (throws ArgError otherwise).  prims in load order.
+// Triangles and quads (a quad is ONE primitive of a leaf), in load order.  Throws std::invalid_argument for an empty scene or
+// coordinates of 1e9 and beyond; the caller (SceneState::buildFast) turns every builder failure into ArgError.
 void buildWideBVH(const std::vector<Primitive>& prims, const WideBVHParams& prm, WideBVH& out);
 
 // The fast walk on the host, decision for decision what ptmi_bounce_wide does per lane: closest hit of one ray.

@@ -148,6 +148,38 @@ def random_scene_with_ply(seed, directory):
     return "\n".join(body + ["WorldEnd"]) + "\n"
 
 
+def random_scene_with_spd(seed, directory):
+    """random_scene plus materials whose "spectrum" parameters name .spd files (written next to the scene): metals with eta / k as
+    pairs or as three numbers, a matte Kd that must be three numbers, comments, quoted numbers, words that are no numbers, an odd
+    count, a file that is not there, an absolute path"""
+    import os
+    rng = np.random.default_rng(20_000 + seed)
+    text = random_scene(seed).rstrip("\n").split("\n")
+    assert text[-1] == "WorldEnd"
+    body = text[:-1]
+
+    def spd(tag):
+        kind = rng.choice(["pairs", "pairs", "pairs", "three", "odd", "word", "quoted", "empty", "missing"], p=[0.3, 0.15, 0.15, 0.15, 0.05, 0.05, 0.05, 0.05, 0.05])
+        name = f"s{seed}_{tag}.spd"
+        n = {"three": 3, "odd": int(rng.choice([1, 5, 7])), "empty": 0}.get(kind, 2 * int(rng.integers(1, 9)))
+        vals = [f"{rng.uniform(300, 800):.4f}" if i % 2 == 0 else f"{rng.uniform(0.05, 5):.5f}" for i in range(n)]
+        if kind == "word" and vals: vals[int(rng.integers(len(vals)))] = "nm"
+        if kind == "quoted" and vals: i = int(rng.integers(len(vals))); vals[i] = '"' + vals[i] + '"'
+        if kind != "missing":
+            with open(os.path.join(directory, name), "w") as f:
+                if rng.random() < 0.5: f.write("# measured data\n")
+                f.write((" " if rng.random() < 0.5 else "\n").join(vals) + ("\n" if rng.random() < 0.7 else ""))
+        return os.path.join(directory, name) if rng.random() < 0.2 else name
+    tri = lambda z: f'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 {z}  1 0 {z}  0 1 {z}]'
+    for k in range(int(rng.integers(1, 4))):
+        r = rng.random()
+        if r < 0.6: m = f'Material "metal" "spectrum eta" "{spd(f"{k}e")}" "spectrum k" "{spd(f"{k}k")}"'
+        elif r < 0.8: m = f'Material "metal" "spectrum eta" "{spd(f"{k}e")}"'
+        else: m = f'Material "matte" "spectrum Kd" "{spd(f"{k}d")}"'
+        body += [m, tri(20 + k)]
+    return "\n".join(body + ["WorldEnd"]) + "\n"
+
+
 def random_scene(seed):
     rng = np.random.default_rng(seed)
     out = ["# fuzz scene %d" % seed, f"LookAt {_vec(rng, 3)} 0 0 0 0 1 0", 'Camera "perspective" "float fov" [45]', "WorldBegin"]

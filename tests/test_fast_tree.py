@@ -447,10 +447,37 @@ def test_certified_walk_soak_against_the_reference_tree_on_the_gpu():
     the radiosity pre-pass: the automatic (certified) walk and the walk over the reference's tree must agree bit for bit."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "certified_soak.py"), "12", "7"], capture_output=True, text=True, timeout=900)
-    print(p.stdout[-1500:])
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "12 scenes: 0 mismatches" in p.stdout
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "certified_soak.py"), "24", "7"], capture_output=True, text=True, timeout=900)
+    print(p.stdout[-4000:])
+    assert p.returncode == 0, p.stdout[-5000:] + p.stderr[-2000:]
+    assert "24 scenes: 0 mismatches" in p.stdout
+    # the hard inputs were really there and really walked by the certified walk
+    for what in ("sheet skimmed at 1e-07 rad", "needles, short edge 1e-08", "stacked layers, 1e-08 rad", "degenerate primitives", "a million units away"):
+        lines = [ln for ln in p.stdout.splitlines() if what in ln]
+        assert lines and all("walk 6:" in ln for ln in lines), what
+
+
+@pytest.mark.gpu
+def test_a_scene_the_builder_declines_renders_and_solves_through_the_references_tree(R):
+    """a scene the 8-wide builder declines (a coordinate of 2e9) loads, renders and runs the radiosity pre-pass through
+    the reference's tree - the automatic choices fall back and do not ask again; a walk asked for by name reports the failure."""
+    args = list(soup(300, 5))
+    args[1] = args[1].copy(); args[1][7, 2] = (2.0e9, 1.0, -3.0)
+    R.load_scene_arrays(*args)
+    assert R.set_traversal(-1) in (R.PHASED, R.PACKED)
+    o = OracleScene.from_arrays(*args)
+    st, ost, nd, same_rgb = render_vs_oracle(R, o, 96, 64, 4, 5)
+    assert nd == 0 and same_rgb
+    R.set_solver_walk(-1, 65)
+    s1 = R.run_radiosity_solver(mc_samples=4, num_iterations=1)
+    s2 = R.run_radiosity_solver(mc_samples=4, num_iterations=1)            # (no second attempt at the tree: same answer)
+    assert s1.walk == 0 and s2.walk == 0
+    with pytest.raises(ptmi.PtmiError):
+        R.set_solver_walk(2, 65); R.run_radiosity_solver(mc_samples=4, num_iterations=1)
+    R.set_solver_walk(-1)
+    with pytest.raises(ptmi.PtmiError):
+        R.set_config(fast_tree=True, spp=1); R.update_resolution(32, 32); R.render_frame()
+    R.set_config(fast_tree=False)
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ import pytest
 
 import ptmi
 from oracle_binding import ref_pbrt_available, ref_pbrt_load
-from pbrt_fuzz import random_scene, random_scene_with_ply
+from pbrt_fuzz import random_scene, random_scene_with_ply, random_scene_with_spd
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PBRT = os.path.join(HERE, "golden", "pbrt")
@@ -51,7 +51,7 @@ def test_fixtures_match_the_committed_goldens():
             same(got, {k: g[k] for k in ("type", "verts", "normal", "bsdf", "Le")}, os.path.basename(f))
             assert (got["type"] == 0).all()              # the importer only ever makes triangles
             n_ok += 1
-    assert n_ok >= 7 and n_rejected >= 5
+    assert n_ok >= 9 and n_rejected >= 9
 
 
 def test_hand_checked_values():
@@ -90,6 +90,14 @@ def test_errors_and_unsupported_constructs(tmp_path):
     assert rejected('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 7] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n')
     assert rejected('WorldBegin\nInclude "nosuchfile.pbrt"\n' + tri + "WorldEnd\n")
     assert rejected('Material "matte"\nWorldBegin\n' + tri + "WorldEnd\n")                # Material outside the world block
+    # "spectrum" parameters from .spd files (Parser.inl:208-224): the file must be there, every token a number, pairs unless three
+    (tmp_path / "ok.spd").write_text("# n\n400 0.2\n500 0.9\n")
+    (tmp_path / "odd.spd").write_text("400 0.2 500 0.9 600\n")
+    (tmp_path / "word.spd").write_text("400 0.2 nm 0.9\n")
+    metal = lambda f: 'WorldBegin\nMaterial "metal" "spectrum eta" "' + f + '"\n' + tri + "WorldEnd\n"
+    assert not rejected(metal("ok.spd")) and not rejected(metal(str(tmp_path / "ok.spd")))     # relative to the scene, or absolute
+    assert rejected(metal("nosuch.spd")) and rejected(metal("odd.spd")) and rejected(metal("word.spd"))
+    assert rejected('WorldBegin\nMaterial "matte" "spectrum Kd" "ok.spd"\n' + tri + "WorldEnd\n")      # four numbers are no RGB value
     assert not rejected("WorldBegin\n" + tri + "WorldEnd\n")
     with pytest.raises(ptmi.PtmiError):
         ptmi.HostScene.load(str(tmp_path / "missing.pbrt"))
@@ -131,6 +139,18 @@ def test_live_against_the_compiled_reference(tmp_path):
             same(got, want, f"ply fuzz seed {seed}")
             n_loaded += 1
     assert n_loaded > 120
+    n_loaded = n_rejected = 0
+    for seed in range(150):                                   # the same scenes plus materials with "spectrum" parameters from .spd files
+        f = tmp_path / f"spdfuzz{seed}.pbrt"
+        f.write_text(random_scene_with_spd(seed, str(tmp_path)))
+        want, got = ref_pbrt_load(str(f)), product_load(str(f))
+        assert (want is None) == (got is None), seed
+        if want is not None:
+            same(got, want, f"spd fuzz seed {seed}")
+            n_loaded += 1
+        else:
+            n_rejected += 1
+    assert n_loaded > 45 and n_rejected > 15
 
 
 @pytest.mark.skipif(not ref_pbrt_available(), reason="oracle/_ref/libptmi_ref_pbrt.so not built (needs /root/reference)")
