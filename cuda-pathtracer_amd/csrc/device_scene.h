@@ -159,7 +159,13 @@ struct CountPublish { int* done_count = nullptr; int* next_count = nullptr; int*
 // takes the next queue entry no lane has taken yet - one atomicAdd on *cursor per scheduling decision with ending lanes.  With
 // max_waves = the waves the device holds at once, no wave of a launch waits for a slot and no lane idles while pixels are queued.
 // (The 8-wide walks; other kernels ignore it.)
-struct LaunchSchedule { int max_waves = 0; int* cursor = nullptr; };
+// cost / cost_max: per-pixel segment counts of this frame and their maximum (the walk adds to them at the end of every visit).
+struct LaunchSchedule { int max_waves = 0; int* cursor = nullptr; unsigned int* cost = nullptr; unsigned int* cost_max = nullptr; };
+// Launch order by cost: queue[0 .. n) = the entries of queue_in (nullptr: 0 .. n - 1) in `classes` (2 .. 256, a power of two)
+// classes of descending cost[entry] (class width cost_max / classes); inside a class the entries keep their order up to the order in
+// which the 256-entry workgroups of the pass reserve their ranges.  hist: 2 x 256 device ints of scratch.  The heaviest pixels of a
+// frame are as long as the frame: started first, they end with it instead of after it.
+void launch_order_by_cost(const int* queue_in, int n, const unsigned int* cost, const unsigned int* cost_max, int* hist, int* queue, int classes, hipStream_t s);
 void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st, const FrameParams& fp,
                    const int* queue_in, int n_in, const int* count_in, int* queue_out, int* count_out, int segments,
                    StatCounters* stats /* nullptr: counters compiled out */,

@@ -360,6 +360,9 @@ struct BounceArgs {
     // cursor != nullptr: queue entries beyond the launch's threads are handed out through *cursor (zero at launch) to lanes whose
     // pixel has finished (the 8-wide walks; LaunchSchedule::refill_waves)
     int* cursor;
+    // cost != nullptr: segments each pixel has taken in this frame, added to at the end of every visit (the next frame's launch
+    // order: heaviest first, RenderState::orderByCost); cost_max: their maximum
+    unsigned int* cost; unsigned int* cost_max;
 };
 
 // Per-lane path registers (the 88-byte HBM record, unpacked).
@@ -637,7 +640,7 @@ __device__ __forceinline__ void publish_count(const BounceArgs& a) {
         __threadfence();
         if (atomicAdd(a.done_count, 1) == (int)(gridDim.x * (kBlock / 64)) - 1) {
             const int c = atomicAdd(a.count_out, 0);
-            atomicExch(a.next_count, 0);
+            atomicExch(a.next_count, 0); atomicExch(a.next_count + 1, 0);      // output count, refill cursor
             atomicExch(a.done_count, 0);
             __hip_atomic_store(a.host_count, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -875,6 +878,7 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 #ifdef PTMI_TRACE_WAVES
 // experiment-only build (tools/wide_trace.py): one 12-word record per wave of ptmi_bounce_wide - start (wall_clock64, low word),
 // duration in ticks, decisions and lanes advanced per kind (NODE / PRIM / SHADE), shader clocks per kind, lanes the wave started with
+// (low byte of the last word; above it: ticks after which fewer than 32 of its lanes still had work, 0 = never)
 constexpr unsigned int kWideTraceCap = 1u << 19;
 __device__ unsigned int g_wt_n;
 __device__ unsigned int g_wt[kWideTraceCap * 12];
@@ -882,7 +886,7 @@ __device__ unsigned int g_wt[kWideTraceCap * 12];
 template <bool STATS, bool GUIDED, bool BATCH, bool CERT, bool QUADS>
 __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     extern __shared__ float4 smem[];
-    PTMI_TR(const unsigned long long wt_t0 = (unsigned long long)wall_clock64(); unsigned int wt_n[3] = {0, 0, 0}, wt_l[3] = {0, 0, 0}; unsigned long long wt_c[3] = {0, 0, 0};)
+    PTMI_TR(const unsigned long long wt_t0 = (unsigned long long)wall_clock64(); unsigned int wt_n[3] = {0, 0, 0}, wt_l[3] = {0, 0, 0}, wt_half = 0; unsigned long long wt_c[3] = {0, 0, 0};)
     const int n_in = a.count_in ? *a.count_in : a.n_in;
     if ((int)(blockIdx.x * kBlock) >= n_in) return;      // grid was sized from a stale (larger) count: nothing to do
     const int idx = blockIdx.x * kBlock + threadIdx.x;
@@ -941,6 +945,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
         // the proof cost a wave iteration per ray and its stragglers waited for a majority: c5tile 1 407 -> 1 455 Msamples/s
         const int c_shade = __popcll(__ballot(phase == PH_SHADE || (CERT && phase >= PH_VERIFY)));
         if (c_node + c_prim + c_shade == 0) break;
+        PTMI_TR(if (!wt_half && c_node + c_prim + c_shade < 32) wt_half = (unsigned int)((unsigned long long)wall_clock64() - wt_t0);)
         PTMI_TR(const int wt_k = c_node >= c_prim && c_node >= c_shade ? 0 : c_prim >= c_shade ? 1 : 2; const long long wt_a = clock64();
                 wt_n[wt_k]++; wt_l[wt_k] += wt_k == 0 ? c_node : wt_k == 1 ? c_prim : c_shade;)
         if (c_node >= c_prim && c_node >= c_shade) {
@@ -1107,6 +1112,11 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     // fewer lanes than queue entries (BounceArgs::cursor) the lane takes the next entry no lane has taken yet.  The
                     // lanes whose visits end in this step share one atomicAdd per counter.
                     store_path(a.st, slot, p);
+                    if (a.cost) {                                      // what this visit cost, for the next frame's launch order
+                        const unsigned int c = a.cost[slot] + (unsigned int)(a.segments - segs_left);
+                        a.cost[slot] = c;
+                        if (!more) atomicMax(a.cost_max, c);
+                    }
                     const int lane = threadIdx.x & 63;
                     const unsigned long long ending = __ballot(1), surviving = __ballot(more);
                     const int first = __ffsll((long long)ending) - 1;
@@ -1147,7 +1157,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                 unsigned int* w = g_wt + 12 * (size_t)i;
                 w[0] = (unsigned int)wt_t0; w[1] = (unsigned int)((unsigned long long)wall_clock64() - wt_t0);
                 w[2] = wt_n[0]; w[3] = wt_l[0]; w[4] = wt_n[1]; w[5] = wt_l[1]; w[6] = wt_n[2]; w[7] = wt_l[2];
-                w[8] = (unsigned int)(wt_c[0] >> 4); w[9] = (unsigned int)(wt_c[1] >> 4); w[10] = (unsigned int)(wt_c[2] >> 4); w[11] = lanes0;
+                w[8] = (unsigned int)(wt_c[0] >> 4); w[9] = (unsigned int)(wt_c[1] >> 4); w[10] = (unsigned int)(wt_c[2] >> 4); w[11] = lanes0 | (wt_half << 8);
             }
         }
     }
@@ -1278,25 +1288,83 @@ void launch_bounce(const DeviceScene& sc, const TileMap& tm, const PathState& st
                    StatCounters* stats, bool many_waves, hipStream_t s, const CountPublish& pub, const LaunchSchedule& sched) {
     if (n_in <= 0) return;
     BounceArgs a{sc, tm, st, fp, queue_in, n_in, count_in, queue_out, count_out, segments, stats, many_waves ? 1 : 0,
-                 pub.done_count, pub.next_count, pub.host_count, nullptr};
+                 pub.done_count, pub.next_count, pub.host_count, nullptr, nullptr, nullptr};
     dim3 grid((n_in + kBlock - 1) / kBlock);
     const bool wide = sc.traversal == TRAVERSAL_WIDE || sc.traversal == TRAVERSAL_CERTIFIED;
     if (wide && sched.max_waves > 0 && sched.cursor) {      // fewer lanes than queue entries: the lanes take the rest through the cursor
         a.cursor = sched.cursor;
         grid.x = std::min<unsigned int>(grid.x, (unsigned int)(sched.max_waves + kBlock / 64 - 1) / (kBlock / 64));
     }
+    if (wide) { a.cost = sched.cost; a.cost_max = sched.cost_max; }
     with_bounce_kernel(a, [&](auto kernel, size_t lds) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, s, a); });
 }
 
 // waves of the frame's bounce kernel that the device holds at once (0: unknown)
 int bounce_resident_waves(const DeviceScene& sc, const FrameParams& fp, bool stats, int n_cus) {
     BounceArgs a{sc, TileMap(), PathState(), fp, nullptr, 0, nullptr, nullptr, nullptr, 0, stats ? reinterpret_cast<StatCounters*>(1) : nullptr, 0,
-                 nullptr, nullptr, nullptr, nullptr};
+                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int blocks = 0;
     with_bounce_kernel(a, [&](auto kernel, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kBlock, lds) != hipSuccess) blocks = 0;
     });
     return blocks * (kBlock / 64) * n_cus;
+}
+
+// ---- launch order by cost (device_scene.h: launch_order_by_cost) ---------------------------------------------------------------
+// class 0 = the heaviest: (255 - floor(256 cost / (cost_max + 1))) >> shift, so ascending classes are descending costs
+__device__ __forceinline__ int cost_class(unsigned int c, unsigned int cmax, int shift) {
+    const unsigned long long k = ((unsigned long long)min(c, cmax) << 8) / ((unsigned long long)cmax + 1ull);
+    return (255 - (int)k) >> shift;
+}
+__global__ __launch_bounds__(kBlock) void ptmi_cost_histogram(const int* __restrict__ queue_in, int n, const unsigned int* __restrict__ cost,
+                                                              const unsigned int* __restrict__ cost_max, int* __restrict__ hist, int shift) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned int cmax = *cost_max;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        atomicAdd(&h[cost_class(cost[queue_in ? queue_in[i] : i], cmax, shift)], 1);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// one workgroup: hist[256 + c] = first position of class c
+__global__ __launch_bounds__(kBlock) void ptmi_cost_offsets(int* __restrict__ hist) {
+    __shared__ int h[256];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int c = 0; c < 256; c++) { const int v = h[c]; h[c] = acc; acc += v; } }
+    __syncthreads();
+    hist[256 + threadIdx.x] = h[threadIdx.x];
+}
+// every workgroup takes 256 consecutive entries, counts its classes, reserves one range per class and places its entries there
+// in their order (so neighbours of one class stay neighbours)
+__global__ __launch_bounds__(kBlock) void ptmi_cost_scatter(const int* __restrict__ queue_in, int n, const unsigned int* __restrict__ cost,
+                                                            const unsigned int* __restrict__ cost_max, int* __restrict__ hist, int* __restrict__ queue, int shift) {
+    __shared__ int h[256], base[256];
+    __shared__ unsigned char cls[kBlock];
+    h[threadIdx.x] = 0;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int entry = i < n ? (queue_in ? queue_in[i] : i) : 0;
+    const int c = i < n ? cost_class(cost[entry], *cost_max, shift) : 255;
+    cls[threadIdx.x] = (unsigned char)c;
+    __syncthreads();
+    if (i < n) atomicAdd(&h[c], 1);
+    int local = 0;                                     // entries of my class before me in this workgroup
+    for (int j = 0; j < (int)threadIdx.x; j++) local += cls[j] == c ? 1 : 0;
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&hist[256 + threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (i < n) queue[base[c] + local] = entry;
+}
+void launch_order_by_cost(const int* queue_in, int n, const unsigned int* cost, const unsigned int* cost_max, int* hist, int* queue, int classes, hipStream_t s) {
+    if (n <= 0) return;
+    int shift = 0;
+    while ((256 >> shift) > classes && shift < 7) shift++;
+    (void)hipMemsetAsync(hist, 0, 512 * sizeof(int), s);
+    const int blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(ptmi_cost_histogram, dim3(std::min(blocks, 1024)), dim3(kBlock), 0, s, queue_in, n, cost, cost_max, hist, shift);
+    hipLaunchKernelGGL(ptmi_cost_offsets, dim3(1), dim3(kBlock), 0, s, hist);
+    hipLaunchKernelGGL(ptmi_cost_scatter, dim3(blocks), dim3(kBlock), 0, s, queue_in, n, cost, cost_max, hist, queue, shift);
 }
 
 void launch_render_init(const TileMap& tm, const PathState& st, const uint32_t* d_jump, uint64_t seed_base, hipStream_t s) {

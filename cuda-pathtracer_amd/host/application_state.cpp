@@ -695,8 +695,10 @@ void SceneState::chooseTraversal() {
 // RenderState
 // ------------------------------------------------------------------------------------------------
 void RenderState::freeBuffers() {
-    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats, d_frame_color};
+    void* ptrs[] = {d_state.A, d_state.B, d_state.C, d_state.D, d_state.E, d_state.F, d_image, d_radiance, d_stats, d_frame_color,
+                    d_cost[0], d_cost[1], d_cost_max, d_cost_hist, d_queue_ordered};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_cost[0] = d_cost[1] = nullptr; d_cost_max = nullptr; d_cost_hist = nullptr; d_queue_ordered = nullptr; cost_valid = false; cost_frame = 0;
     d_frame_color = nullptr; frame_color_frames = 0; batch_frames = 1; batch_spp = 0;
     if (h_image) { (void)hipHostFree(h_image); h_image = nullptr; }
     freeChunks();
@@ -731,9 +733,9 @@ void RenderState::setupChunks(int n) {
         ch.d_queue_init = (int*)hipMallocSafe(cap, "chunk.queue_init");
         ch.d_queue[0] = (int*)hipMallocSafe(cap, "chunk.queue0");
         ch.d_queue[1] = (int*)hipMallocSafe(cap, "chunk.queue1");
-        // per ring slot i: [2 i] the launch's output count, [2 i + 1] its refill cursor; [2 kCountRing]: the launch's arrival counter
-        ch.d_count = (int*)hipMallocSafe((2 * kCountRing + 1) * sizeof(int), "chunk.count");
-        PTMI_HIP(hipMemset(ch.d_count, 0, (2 * kCountRing + 1) * sizeof(int)));
+        // per ring slot i: [4 i] the launch's output count, [4 i + 1] its refill cursor, [4 i + 2] its finished pixels; [4 kCountRing]: the launch's arrival counter
+        ch.d_count = (int*)hipMallocSafe((4 * kCountRing + 1) * sizeof(int), "chunk.count");
+        PTMI_HIP(hipMemset(ch.d_count, 0, (4 * kCountRing + 1) * sizeof(int)));
         // coherent (fine-grained) host memory: with count publishing the device stores into it while the kernel runs
         PTMI_HIP(hipHostMalloc((void**)&ch.h_count, kCountRing * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
         PTMI_HIP(hipHostGetDevicePointer((void**)&ch.d_hcount, ch.h_count, 0));
@@ -757,6 +759,10 @@ void RenderState::allocateBuffers() {
     d_image = (unsigned char*)hipMallocSafe(n * 3, "d_image");
     d_radiance = (float*)hipMallocSafe(n * 3 * sizeof(float), "d_radiance");
     d_stats = (StatCounters*)hipMallocSafe(sizeof(StatCounters), "d_stats");
+    for (int k = 0; k < 2; k++) d_cost[k] = (unsigned int*)hipMallocSafe(n * sizeof(unsigned int), "d_cost");
+    d_cost_max = (unsigned int*)hipMallocSafe(2 * sizeof(unsigned int), "d_cost_max");
+    d_cost_hist = (int*)hipMallocSafe(512 * sizeof(int), "d_cost_hist");
+    d_queue_ordered = (int*)hipMallocSafe(n * sizeof(int), "d_queue_ordered");
     PTMI_HIP(hipHostMalloc((void**)&h_image, n * 3));                     // h_image = new unsigned char[img_size], application_state.h:99
     setupChunks(want_chunks > 0 ? std::min(want_chunks, (int)kMaxChunks) : (n_local >= (size_t)(1 << 18) ? 2 : 1));
 
@@ -927,9 +933,16 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     // a lane whose pixel has had its visit takes the next queued pixel - no wave waits for a slot, no lane idles while pixels are
     // queued, and the frame needs no launch boundary to re-pack its lanes before the queue has run dry
     bool refill = (trav == TRAVERSAL_WIDE || trav == TRAVERSAL_CERTIFIED) && g.config.segments_per_launch <= 0 && wave_slots > 0;
-    int refill_segments = kRestOfFrameSegments;
-    if (const char* e = getenv("PTMI_REFILL")) refill = refill && e[0] != '0';                      // A/B hooks of round 4
-    if (const char* e = getenv("PTMI_REFILL_SEGMENTS")) refill_segments = std::max(1, atoi(e));
+    const int refill_segments = kRestOfFrameSegments;
+    // launch order by last frame's cost (below): in 16 classes, and only while the frame has at most three pixels per lane of the
+    // launch - an eighth of the 1 M-triangle frame (1.3 per lane) gains 9 % at 64 spp and 12 % at 2048 spp; the whole frame (10.7
+    // per lane) has no tail to speak of and loses 6 % with its launch order torn from the image order (neighbouring waves share
+    // the lines of the scene they fetch).  Classes 2 / 4 / 8 / 16 / 32 / 64 / 256 on the eighth at 64 spp: 1 681 / 1 685 / 1 879 / 1 897 /
+    // 1 875 / 1 860 / 1 819 Msamples/s against 1 735 in image order.
+    bool order_by_cost = (long long)r.n_local <= 3ll * 64 * wave_slots;
+    int order_classes = 16;
+    if (const char* e = getenv("PTMI_REFILL")) refill = refill && e[0] != '0';                      // A/B hooks of round 4 (tools/occupancy_probe.py)
+    if (const char* e = getenv("PTMI_ORDER")) { order_by_cost = e[0] != '0'; if (atoi(e) > 1) order_classes = atoi(e); }
     // With refill one launch keeps every wave slot busy by itself: a second chunk's kernel only competes with it (an eighth of the
     // 1 M-triangle frame 1 661 -> 1 716 Msamples/s with one chunk, the whole frame 2 600 -> 2 795; three chunks: 1 628 / 2 501).  The
     // automatic choice follows the walk; a forced count (config.streams) stays.
@@ -968,6 +981,24 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
 
     launch_frame_begin(r.tile, r.d_state, fp, s);
 
+    // Launch order of a refill frame: the pixels that took the most segments in the last frame first.  A pixel has ONE path in
+    // flight, so the heaviest pixels are as long as the frame whatever the GPU does meanwhile; started last - in image order the
+    // top rows of the tile are taken when the first background pixels are through - they end a background pixel's length after
+    // the rest.  The costs are the last frame's (same pixels, usually the same view); a first frame runs in image order.
+    const int* first_queue = nullptr;
+    unsigned int *cost_now = nullptr, *cost_max_now = nullptr;
+    if (refill && r.n_chunks == 1 && n_frames == 1 && order_by_cost) {
+        const int cur = (int)(r.cost_frame & 1), prev = cur ^ 1;
+        if (r.cost_valid) {
+            launch_order_by_cost(r.chunk[0].d_queue_init, r.chunk[0].n, r.d_cost[prev], r.d_cost_max + prev, r.d_cost_hist, r.d_queue_ordered, order_classes, s);
+            first_queue = r.d_queue_ordered;
+        }
+        PTMI_HIP(hipMemsetAsync(r.d_cost[cur], 0, std::max<size_t>(r.n_local, 1) * sizeof(unsigned int), s));
+        PTMI_HIP(hipMemsetAsync(r.d_cost_max + cur, 0, sizeof(unsigned int), s));
+        cost_now = r.d_cost[cur]; cost_max_now = r.d_cost_max + cur;
+        r.cost_valid = false;                          // until this frame is through
+    }
+
     // queue-driven loop: every launch advances each active pixel of its chunk by `segments` ray segments and compacts.
     // A launch reads its exact input count from device memory (the previous launch's output counter), so the host
     // does not wait for each count: per chunk it runs kRunAhead launches ahead, sizing grids with the newest count it
@@ -982,7 +1013,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
         run[c].bound = r.chunk[c].n; run[c].finished = r.chunk[c].n == 0;
         for (int i = 0; i < kRing; i++) run[c].done[i] = event(n_ev++);
         PTMI_HIP(hipStreamWaitEvent(r.chunk[c].stream, ev_ready, 0));
-        if (publish) PTMI_HIP(hipMemsetAsync(r.chunk[c].d_count, 0, (2 * kRing + 1) * sizeof(int), r.chunk[c].stream));   // once per frame
+        if (publish) PTMI_HIP(hipMemsetAsync(r.chunk[c].d_count, 0, (4 * kRing + 1) * sizeof(int), r.chunk[c].stream));   // once per frame
     }
     uint64_t launches = 0, visits = 0;
     const size_t first_pair_event = n_ev;
@@ -994,9 +1025,9 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                 const int slot_out = u.issued % kRing;
                 CountPublish pub;
                 if (publish) {
-                    pub.done_count = ch.d_count + 2 * kRing; pub.next_count = ch.d_count + 2 * ((slot_out + 1) % kRing); pub.host_count = ch.d_hcount + slot_out;
+                    pub.done_count = ch.d_count + 4 * kRing; pub.next_count = ch.d_count + 4 * ((slot_out + 1) % kRing); pub.host_count = ch.d_hcount + slot_out;
                     __atomic_store_n(ch.h_count + slot_out, -1, __ATOMIC_RELEASE);      // "not there yet"
-                } else PTMI_HIP(hipMemsetAsync(ch.d_count + 2 * slot_out, 0, 2 * sizeof(int), ch.stream));     // output count and refill cursor
+                } else PTMI_HIP(hipMemsetAsync(ch.d_count + 4 * slot_out, 0, 4 * sizeof(int), ch.stream));     // output count, refill cursor, finished pixels
                 const hipEvent_t e0 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e0, ch.stream));
                 long long active = 0;                   // pixels still in flight, as far as the host has seen (counts only shrink)
@@ -1007,17 +1038,18 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
                     // this chunk's share of the device's wave slots, by its share of the pixels still in flight (rounded down: the
                     // chunks together must not ask for more waves than fit at once, or the surplus starts a whole launch late)
                     sched.max_waves = std::max(4, (int)(wave_slots * (long long)u.bound / active) & ~3);
-                    sched.cursor = ch.d_count + 2 * slot_out + 1;
+                    sched.cursor = ch.d_count + 4 * slot_out + 1;
+                    sched.cost = cost_now; sched.cost_max = cost_max_now;
                 }
-                launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? ch.d_queue_init : ch.d_queue[(u.issued - 1) & 1], u.bound,
-                              u.issued == 0 ? nullptr : ch.d_count + 2 * ((u.issued - 1) % kRing), ch.d_queue[u.issued & 1], ch.d_count + 2 * slot_out,
+                launch_bounce(scene, r.tile, r.d_state, fp, u.issued == 0 ? (first_queue ? first_queue : ch.d_queue_init) : ch.d_queue[(u.issued - 1) & 1], u.bound,
+                              u.issued == 0 ? nullptr : ch.d_count + 4 * ((u.issued - 1) % kRing), ch.d_queue[u.issued & 1], ch.d_count + 4 * slot_out,
                               refill ? refill_segments : fits ? rest_segments : segments, want_stats ? r.d_stats : nullptr,
                               phased && wave_slots > 0 && (active + 63) / 64 >= 2 * wave_slots, ch.stream, pub, sched);
                 PTMI_HIP(hipGetLastError());           // launch-time failures (bad LDS size, ...) surface here, not a frame later
                 const hipEvent_t e1 = stats ? event(n_ev++) : nullptr;
                 if (stats) PTMI_HIP(hipEventRecord(e1, ch.stream));
                 if (!publish) {
-                    PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + 2 * slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
+                    PTMI_HIP(hipMemcpyAsync(ch.h_count + slot_out, ch.d_count + 4 * slot_out, sizeof(int), hipMemcpyDeviceToHost, ch.stream));
                     PTMI_HIP(hipEventRecord(u.done[slot_out], ch.stream));
                 }
                 u.issued++;
@@ -1068,6 +1100,7 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     PTMI_HIP(hipGetLastError());
     drain.armed = false;
     r.batch_frames = n_frames; r.batch_spp = g.config.spp;
+    if (cost_now) { r.cost_valid = true; r.cost_frame++; }
 
     if (stats) {
         float ms = 0.0f;

@@ -185,6 +185,14 @@ struct RenderState {
     int n_chunks = 1;
     int want_chunks = 0;                             // 0 = automatic, else forced (scheduling knob)
     StatCounters* d_stats = nullptr;
+    // launch order by cost (refill launches): the segments every pixel took in the last frame and in the one being rendered
+    // (d_cost[frame & 1], n_local each, + their maxima), the scratch of the ordering pass and the ordered queue
+    unsigned int* d_cost[2] = {nullptr, nullptr};
+    unsigned int* d_cost_max = nullptr;              // [2]
+    int* d_cost_hist = nullptr;                      // 512
+    int* d_queue_ordered = nullptr;                  // n_local
+    unsigned long long cost_frame = 0;               // frames rendered with cost accounting since allocateBuffers
+    bool cost_valid = false;                         // d_cost[(cost_frame - 1) & 1] holds a whole frame's costs of the pixels as they are numbered now
     uint32_t* d_jump = nullptr;                      // XORWOW skip-ahead matrices (owned by the ctx, set before allocateBuffers)
     uint64_t seed_base = 2023;
     hipStream_t stream = nullptr;

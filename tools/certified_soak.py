@@ -63,12 +63,12 @@ def hard_scene(kind, it):
             for j in range(g):
                 t.append([P(i, j), P(i + 1, j), P(i + 1, j + 1)]); t.append([P(i, j), P(i + 1, j + 1), P(i, j + 1)])
         t.append([(4.5, -3, -6), (4.5, 6, -6), (4.5, 6, 6)]); t.append([(4.5, -3, -6), (4.5, 6, 6), (4.5, -3, 6)])
-        tilt = [1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3][it % 6]
+        tilt = [1e-7, 1e-5, 1e-3, 1e-6, 3e-7, 1e-4][it % 6]
         h = 1.5e-3 + tilt * 4.0
         cam.origin[:] = (-4.4, h, 0.37); cam.lookat[:] = (4.4, h - tilt * 8.8, 0.41); cam.vfov_deg = 0.02
         return finish(*tris(t)), cam, f"sheet skimmed at {tilt:g} rad"
     if kind == 5:                                # a fence of 4 096 needles (short edge 1e-8 .. 1e-5, pitch twice that) in front of a soup
-        w = [1e-8, 1e-7, 1e-6, 1e-5][it % 4]
+        w = [1e-8, 1e-6, 1e-5, 1e-7][it % 4]
         k = np.arange(4096)
         x0 = (k * 2.0 * w).astype(np.float64)
         t = [[(x, 1.0, -1.0), (x + w, 1.0, -1.0), (x, 2.0, -1.0 + (1e-3 if i % 2 else 0.0))] for i, x in enumerate(x0)]
@@ -98,7 +98,7 @@ def hard_scene(kind, it):
         ty, tv = tris(t)
         sy, sv = soup(300, 1)
         sv[:, :, 1] += 1.0
-        tilt = [1e-8, 1e-7, 1e-6, 1e-5][it % 4]
+        tilt = [1e-8, 1e-6, 1e-5, 1e-7][it % 4]
         h = 2.5e-4 + (it % 3) * 1e-4
         cam.origin[:] = (-7.0, h, 0.2); cam.lookat[:] = (7.0, h - tilt * 14.0, 0.3); cam.vfov_deg = 0.002
         return finish(np.concatenate([ty, sy]), np.concatenate([tv, sv])), cam, f"stacked layers, {tilt:g} rad"
@@ -109,6 +109,7 @@ def hard_scene(kind, it):
     return finish(np.concatenate([ty, oy]), np.concatenate([tv, ov])), cam, "one primitive a million units away"
 
 
+seen = {}
 kinds = [0, 1, 2, 3] if n_scenes <= 8 else [0, 1, 2, 3, 4, 5, 6, 7, 8, 4, 5, 7]
 for it in range(n_scenes):
     kind = kinds[it % len(kinds)]               # 0 generic soup, 1 triangles only, 2 axis-aligned (flat boxes), 3 with duplicates (ties), 4 .. 8: hard_scene
@@ -119,7 +120,8 @@ for it in range(n_scenes):
         cam = ptmi.default_camera()
         cam.origin[:] = (rng.uniform(-1, 1), rng.uniform(1, 4), rng.uniform(2, 9) if it % 5 else 40.0)     # every fifth camera far away
     else:
-        arrays, cam, note = hard_scene(kind, it // len(kinds) + it)
+        seen[kind] = seen.get(kind, -1) + 1           # the k-th scene of its kind takes the k-th value of the kind's list (hardest first)
+        arrays, cam, note = hard_scene(kind, seen[kind])
     types = arrays[0]; n = len(types)
     R.load_scene_arrays(*arrays)
     R.set_camera(cam)

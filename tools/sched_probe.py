@@ -30,7 +30,7 @@ for share in shares:
     for v in variants:
         f = v.split(":"); budget, sparse, seg = f[0], f[1], int(f[2]) if len(f) > 2 else 0
         streams = int(f[3]) if len(f) > 3 else 0
-        os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"; os.environ["PTMI_REFILL_SEGMENTS"] = budget if int(budget) > 0 else "65536"
+        os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"
         r.set_config(spp=spp, max_depth=depth, segments_per_launch=seg, collect_stats=False, streams=streams)
         setup(share)
         r.render_frame()

@@ -23,13 +23,14 @@ def read():
     return buf[:min(n, cap)].copy()
 for v in variants:
     budget, sparse = v.split(":")
-    os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"; os.environ["PTMI_REFILL_SEGMENTS"] = budget if int(budget) > 0 else "65536"
+    os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"
     r.set_config(spp=spp, max_depth=8, collect_stats=False)
     r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
     r.render_frame(); read()
     r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
     t0 = time.perf_counter(); st = r.render_frame(); dt = time.perf_counter() - t0
     w = read().astype(np.int64)
+    half = w[:, 11] >> 8; w[:, 11] &= 0xff
     start = (w[:, 0] - w[:, 0].min()) & 0xffffffff
     start = start - start.min()
     end = start + w[:, 1]
@@ -44,6 +45,8 @@ for v in variants:
         occ[b] = ov.sum() / (hi - lo); lanes[b] = (ov * w[:, 11]).sum() / max(ov.sum(), 1)
     print("  resident waves per %.2f ms bin: " % binw + " ".join(f"{int(x)}" for x in occ))
     print("  starting lanes per resident wave: " + " ".join(f"{x:.0f}" for x in lanes))
+    hs = np.sort(np.where(half > 0, start + half, end)) * 1e-5
+    print("  time (ms) by which 10 / 25 / 50 / 75 / 90 / 99 % of the waves were less than half full: " + " ".join(f"{hs[int(q * (len(hs) - 1))]:.2f}" for q in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99)))
     print(f"  mean resident waves {(w[:, 1].sum() / (T * 1e5)):.0f}; wave duration mean {w[:, 1].mean()*1e-2:.0f} us, max {w[:, 1].max()*1e-2:.0f} us")
     names = ["NODE", "PRIM", "SHADE"]
     tot_clk = sum(w[:, 8 + k].sum() * 16 for k in range(3))
