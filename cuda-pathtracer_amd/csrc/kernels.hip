@@ -647,6 +647,35 @@ __device__ __forceinline__ void publish_count(const BounceArgs& a) {
     }
 }
 
+// The end of a pixel's VISIT to a launch: all its samples are done (!more), or it has had its a.segments segments of this launch.
+// Its state goes back to HBM; a pixel that is not through joins the output queue; and when the launch has fewer lanes than queue
+// entries (BounceArgs::cursor) the lane takes the next entry no lane has taken yet - true: `slot` / `p` hold that pixel, with
+// segs_left segments to go.  Call from the lanes whose visits end now (divergent code): they share one atomicAdd per counter.
+__device__ __forceinline__ bool end_visit(const BounceArgs& a, int n_in, bool more, int& slot, PathRegs& p, int& segs_left) {
+    store_path(a.st, slot, p);
+    if (a.cost) {                                      // what this visit cost, for the next frame's launch order
+        const unsigned int c = a.cost[slot] + (unsigned int)(a.segments - segs_left);
+        a.cost[slot] = c;
+        if (!more) atomicMax(a.cost_max, c);
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ending = __ballot(1), surviving = __ballot(more);
+    const int first = __ffsll((long long)ending) - 1;
+    int out_base = 0, in_base = 0;
+    if (lane == first) {
+        if (surviving) out_base = atomicAdd(a.count_out, __popcll(surviving));
+        if (a.cursor) in_base = atomicAdd(a.cursor, __popcll(ending));
+    }
+    out_base = __shfl(out_base, first); in_base = __shfl(in_base, first);
+    if (more) a.queue_out[out_base + __popcll(surviving & ((1ull << lane) - 1ull))] = slot;
+    const int entry = (int)(gridDim.x * kBlock) + in_base + __popcll(ending & ((1ull << lane) - 1ull));
+    if (!(a.cursor && entry < n_in)) return false;
+    slot = a.queue_in ? a.queue_in[entry] : entry;
+    load_path(a.st, a.tm, slot, p);
+    segs_left = a.segments;
+    return true;
+}
+
 // ---- ptmi_bounce: segment-synchronous form (SWEEP and STACK walks) ------------------------------------------------
 // Every wave traces one ray segment per lane, then shades, K times.  LDS: [nodes | prims | mats] when LDS_GEOM (always
 // for SWEEP), then the traversal stacks (STACK only).
@@ -1107,32 +1136,8 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     if (STATS) cn.rays++;
                     if (CERT && !origin_in_range()) phase = PH_EXACT;
                 } else {
-                    // This pixel's visit is over: all its samples are done, or it has had its a.segments segments of this launch.
-                    // Its state goes back to HBM; a pixel that is not through joins the output queue; and when the launch has
-                    // fewer lanes than queue entries (BounceArgs::cursor) the lane takes the next entry no lane has taken yet.  The
-                    // lanes whose visits end in this step share one atomicAdd per counter.
-                    store_path(a.st, slot, p);
-                    if (a.cost) {                                      // what this visit cost, for the next frame's launch order
-                        const unsigned int c = a.cost[slot] + (unsigned int)(a.segments - segs_left);
-                        a.cost[slot] = c;
-                        if (!more) atomicMax(a.cost_max, c);
-                    }
-                    const int lane = threadIdx.x & 63;
-                    const unsigned long long ending = __ballot(1), surviving = __ballot(more);
-                    const int first = __ffsll((long long)ending) - 1;
-                    int out_base = 0, in_base = 0;
-                    if (lane == first) {
-                        if (surviving) out_base = atomicAdd(a.count_out, __popcll(surviving));
-                        if (a.cursor) in_base = atomicAdd(a.cursor, __popcll(ending));
-                    }
-                    out_base = __shfl(out_base, first); in_base = __shfl(in_base, first);
-                    if (more) a.queue_out[out_base + __popcll(surviving & ((1ull << lane) - 1ull))] = slot;
-                    const int entry = (int)(gridDim.x * kBlock) + in_base + __popcll(ending & ((1ull << lane) - 1ull));
                     phase = PH_DONE;
-                    if (a.cursor && entry < n_in) {
-                        slot = a.queue_in ? a.queue_in[entry] : entry;
-                        load_path(a.st, a.tm, slot, p);
-                        segs_left = a.segments;
+                    if (end_visit(a, n_in, more, slot, p, segs_left)) {            // the lane goes on with the next queued pixel
                         slot_hit = -1; closest_t = FLT_MAX; sp = 0; t_mask = 0u;
                         inv = mk3(wide_inv(p.d.x), wide_inv(p.d.y), wide_inv(p.d.z));
                         octinv = wide_octinv(inv);
