@@ -1419,7 +1419,105 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
 }
 
 // ---------------------------------------------------------------------------------------------
+// The certified closest hit of ONE ray, lane by lane (no phases): the walk and the proof of bounce_wide_body<..., CERT> in
+// straight-line form, for callers that trace a ray at a time (the Radiosity view).  Returns the REFERENCE's hit: its leaf-order
+// slot in ref_slot, so that the caller indexes the reference's per-primitive arrays.  stack: this lane's column of w_depth
+// 8-byte entries in LDS (entry e at stack[e * kBlock]).
+// ---------------------------------------------------------------------------------------------
+template <bool QUADS>
+__device__ __forceinline__ bool certified_closest_hit(const DeviceScene& sc, uint2* stack, f3 o, f3 d, float t_min, float& t_hit, int& ref_slot) {
+    LaneCounters cn = {0, 0, 0, 0, 0, 0, 0};
+    auto reference_walk = [&]() { return intersect_lane<QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, true, o, d, t_min, FLT_MAX, t_hit, ref_slot, cn); };
+    if (fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) > sc.w_guard) return reference_walk();      // the boxes are not padded for this origin
+    const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
+    const uint32_t octinv = wide_octinv(inv);
+    const float t_lo = mt_t_lo(t_min);
+    float closest_t = FLT_MAX;
+    int slot_hit = -1, sp = 0;
+    bool tie = false;
+    uint32_t g_base = 0u, g_bits = (1u << 8) | (1u << octinv);
+    while (true) {
+        if ((g_bits & 0xffu) == 0u) {
+            if (sp == 0) break;
+            sp--; const uint2 e = stack[sp * kBlock]; g_base = e.x; g_bits = e.y;
+        }
+        const int bit = 31 - __clz((int)(g_bits & 0xffu));
+        g_bits ^= 1u << bit;
+        const uint32_t child = (uint32_t)bit ^ octinv;
+        const uint32_t ni = g_base + (uint32_t)__popc((g_bits >> 8) & ((1u << child) - 1u));
+        if (g_bits & 0xffu) { stack[sp * kBlock] = make_uint2(g_base, g_bits); sp++; }
+        const uint4* q = sc.wnodes + 8 * (size_t)ni;
+        const WideStep st = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], o, inv, octinv, t_min, closest_t);
+        uint32_t tris = st.tris;
+        while (tris) {
+            const int k = (int)st.tri_base + __ffs((int)tris) - 1;
+            tris &= tris - 1u;
+            float tt = 0.0f;
+            bool ok;
+            if (QUADS && __float_as_int(sc.wqprims[4 * (size_t)k].w) != 0) {               // a quad: the smaller t of its two halves
+                const float4* r = sc.wqprims + 4 * (size_t)k;
+                const float eps_up = __uint_as_float(__float_as_uint(1e-8f) + 1u);
+                tt = min_raw(mt_candidate(xyz(r[0]), xyz(r[1]), xyz(r[2]), o, d, eps_up, t_lo), mt_candidate(xyz(r[0]), xyz(r[2]), xyz(r[3]), o, d, eps_up, t_lo));
+                ok = tt < __builtin_inff();
+            } else if (QUADS) {
+                const float4* r = sc.wqprims + 4 * (size_t)k;
+                ok = mt_hit(xyz(r[0]), xyz(r[1]), xyz(r[2]), o, d, 1e-8f, t_lo, tt);
+            } else {
+                const f3p* r = reinterpret_cast<const f3p*>(sc.wprims) + 3 * (size_t)k;
+                const f3p v0 = r[0], e1 = r[1], e2 = r[2];
+                ok = mt_hit(mk3(v0.x, v0.y, v0.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), o, d, 1e-8f, t_lo, tt);
+            }
+            if (ok) {
+                if (tt < closest_t) { closest_t = tt; slot_hit = k; tie = false; }
+                else if (tt == closest_t && slot_hit >= 0) tie = true;             // the reference keeps the hit it visits first: let it decide
+            }
+        }
+        g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
+    }
+    if (slot_hit < 0) return false;                        // the reference can only accept triangles this walk would have found
+    if (tie) return reference_walk();
+    // the proof (bounce_wide_body, VERIFY): the hit point inside the hit leaf's box of the reference's tree by eps, else the exact
+    // slab tests of the leaf's ancestors, leaf first, up to the first box that holds the point with the margin
+    const float4 lo = sc.wcert[2 * (size_t)slot_hit], hi = sc.wcert[2 * (size_t)slot_hit + 1];
+    const f3 q = o + closest_t * d;
+    const float kEps = 9.5367431640625e-7f, kSlope = 8.673617379884035e-19f;
+    const bool slopes = fabsf(d.x) >= kSlope && fabsf(d.y) >= kSlope && fabsf(d.z) >= kSlope;
+    {
+        const float ex = kEps * (fabsf(o.x) + fmaxf(fabsf(lo.x), fabsf(hi.x))), ey = kEps * (fabsf(o.y) + fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                    ez = kEps * (fabsf(o.z) + fmaxf(fabsf(lo.z), fabsf(hi.z)));
+        const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
+        if (!(inside && slopes)) {
+            const f3 rinv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));            // the reference's 1 / d for its slab tests
+            const uint32_t ref = __float_as_uint(lo.w);
+            uint32_t off = ref >> 5;
+            bool proven = false, failed = false;
+            for (int left = (int)(ref & 31u); left > 0 && !proven && !failed; left--, off++) {
+                const uint4 idx = sc.wanc[off];
+                const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];              // padding repeats the root
+                    const float4 n0 = sc.nodes[2 * (size_t)j], n1 = sc.nodes[2 * (size_t)j + 1];
+                    const float nx = kEps * (fabsf(o.x) + fmaxf(fabsf(n0.x), fabsf(n1.x))), ny = kEps * (fabsf(o.y) + fmaxf(fabsf(n0.y), fabsf(n1.y))),
+                                nz = kEps * (fabsf(o.z) + fmaxf(fabsf(n0.z), fabsf(n1.z)));
+                    const bool holds = slopes && q.x - n0.x >= nx && n1.x - q.x >= nx && q.y - n0.y >= ny && n1.y - q.y >= ny && q.z - n0.z >= nz && n1.z - q.z >= nz;
+                    const bool passes = box_hit(n0, n1, o, rinv, t_min, closest_t);
+                    failed = failed || (!proven && !holds && !passes);
+                    proven = proven || holds;
+                }
+            }
+            if (failed) return reference_walk();
+        }
+    }
+    t_hit = closest_t;
+    ref_slot = sc.wref_slot[slot_hit];
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // render_radiosity (integrator.h:460-504): a visualisation pass, one thread per pixel, not performance-critical
+// MODE TRAVERSAL_CERTIFIED: the first hit through the certified walk (scenes above the sweep's 64 primitives: the 8-wide tree + the
+// proof per hit, else the reference's walk - the reference's hit for every ray); TRAVERSAL_LANE / TRAVERSAL_STACK: the reference's walk
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool HAS_QUADS>
 __global__ __launch_bounds__(kBlock) void ptmi_render_radiosity(DeviceScene sc, TileMap tm, PathState st, FrameParams fp,
@@ -1442,7 +1540,9 @@ __global__ __launch_bounds__(kBlock) void ptmi_render_radiosity(DeviceScene sc, 
         f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         if (live) camera_ray(fp, tm, x, y, rng, o, d);
         float t = 0.0f; int k = -1;
-        const bool hit = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, o, d, 1e-4f, FLT_MAX, t, k, cn);
+        bool hit;
+        if constexpr (MODE == TRAVERSAL_CERTIFIED) hit = live && certified_closest_hit<HAS_QUADS>(sc, reinterpret_cast<uint2*>(smem) + threadIdx.x, o, d, 1e-4f, t, k);
+        else hit = scene_intersect<MODE, HAS_QUADS, false>(sc.nodes, sc.prims, sc.prim_stride, sc.n_nodes, stack, live, o, d, 1e-4f, FLT_MAX, t, k, cn);
         if (live && hit) {
             color = color + xyz(sc.mats[3 * k + 2]);                                  // color += si.Le
             color = color + (sc.radiosity ? xyz(sc.radiosity[k]) : mk3(0.0f, 0.0f, 0.0f));   // color += prim->getRadiosity()
@@ -1469,9 +1569,11 @@ void launch_render_radiosity(const DeviceScene& sc, const TileMap& tm, const Pat
     if (n <= 0) return;
     const dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     const bool deep = sc.traversal == TRAVERSAL_STACK;                                // per-lane walk from global memory; stack only for deep trees
-    const size_t lds = deep ? (size_t)sc.stack_entries * kBlock * sizeof(int) : 0;
+    const bool cert = sc.traversal == TRAVERSAL_CERTIFIED && sc.wnodes && sc.wcert && sc.wanc && sc.wref_slot && (!sc.has_quads || sc.wqprims);
+    const size_t lds = cert ? (size_t)sc.w_depth * kBlock * sizeof(uint2) : deep ? (size_t)sc.stack_entries * kBlock * sizeof(int) : 0;
 #define PTMI_RAD(M_, Q_) hipLaunchKernelGGL((ptmi_render_radiosity<M_, Q_>), grid, block, lds, s, sc, tm, st, fp, rgb8, radiance)
-    if (deep) { if (sc.has_quads) PTMI_RAD(TRAVERSAL_STACK, true); else PTMI_RAD(TRAVERSAL_STACK, false); }
+    if (cert) { if (sc.has_quads) PTMI_RAD(TRAVERSAL_CERTIFIED, true); else PTMI_RAD(TRAVERSAL_CERTIFIED, false); }
+    else if (deep) { if (sc.has_quads) PTMI_RAD(TRAVERSAL_STACK, true); else PTMI_RAD(TRAVERSAL_STACK, false); }
     else { if (sc.has_quads) PTMI_RAD(TRAVERSAL_LANE, true); else PTMI_RAD(TRAVERSAL_LANE, false); }
 #undef PTMI_RAD
 }

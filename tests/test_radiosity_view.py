@@ -129,3 +129,36 @@ def test_gpu_radiosity_view_tiles_and_errors(R):
         R.set_config(integrator=2)
     R.set_config(integrator=0); R.set_radiosity(None)
     R.update_resolution(W, H)
+
+
+@pytest.mark.gpu
+def test_gpu_radiosity_view_through_the_certified_walk_on_the_1m_triangle_scene(R):
+    """Scenes above the sweep's 64 primitives trace the view's first hits through the certified walk: on the
+    1 048 576-triangle scene two bands of rows against the oracle, and the whole 1024^2 frame against the walk over the reference's
+    own tree on the GPU - bit for bit, per-primitive radiosities included (they are indexed by the reference's leaf-order slot)."""
+    import time
+    import ptmi_scenes
+    import ptmi
+    base = ptmi.HostScene.load(os.path.join(SCENES, "cbox_quads.obj")).prims()
+    sc = ptmi_scenes.tessellated_cornell(base, 256, 128, seed=1)
+    args = (sc["type"], sc["verts"], sc["normal"], sc["bsdf"], sc["Le"])
+    R.load_scene_arrays(*args)
+    assert R.set_traversal(-1) == R.CERTIFIED
+    o = OracleScene.from_arrays(*args)
+    W = H = 1024; spp = 3
+    rad_in = np.random.default_rng(2).random((o.n_prims, 3)).astype(F)
+    R.set_radiosity(rad_in); o.set_radiosity(rad_in)
+    R.update_resolution(W, H); R.set_config(spp=spp, integrator=1)
+    t0 = time.perf_counter(); R.render_frame(); t_cert = time.perf_counter() - t0
+    rgb, rad = R.read_image()
+    R.set_traversal(R.PACKED)                                   # the reference's tree, node for node
+    R.update_resolution(W, H)
+    t0 = time.perf_counter(); R.render_frame(); t_ref = time.perf_counter() - t0
+    rgb2, rad2 = R.read_image()
+    R.set_traversal(-1)
+    assert (bits(rad) == bits(rad2)).all() and (rgb == rgb2).all(), f"{(bits(rad) != bits(rad2)).any(axis=-1).sum()} pixels differ between the two walks"
+    for y0 in (300, 700):
+        orgb, orad = o.render_radiosity(default_camera(), W, H, spp, y0=y0, y1=y0 + 4)
+        assert (bits(rad[y0:y0 + 4]) == bits(orad[y0:y0 + 4])).all() and (rgb[y0:y0 + 4] == orgb[y0:y0 + 4]).all()
+    print(f"radiosity view, 1 M triangles, 1024^2 x {spp} spp: certified walk {t_cert * 1e3:.1f} ms, reference's tree {t_ref * 1e3:.1f} ms")
+    R.set_config(integrator=0); R.set_radiosity(None)
