@@ -876,28 +876,32 @@ __global__ __launch_bounds__(kBlock, 8) __attribute__((amdgpu_num_sgpr(80))) voi
 // Measured and dropped: a UNIFIED step (a lane's pending triangle and its next node fetched and tested in one step, two phases
 // to vote between): 92 registers, 5 waves per SIMD: 1 610 / 2 322 Msamples/s (an eighth / the whole 1 M-triangle frame) against
 // 1 719 / 2 405 for this form at 6 waves; bounded to 6 waves it spills inside the loop (867 / 1 100).
-// CERT (TRAVERSAL_CERTIFIED): the same walk made EXACT.  The fast walk tests every triangle whose Moller-Trumbore test accepts
-// the ray up to the current closest_t (its boxes are conservative), with the reference's arithmetic; so its hit (t*, k*) is
-// the global minimum over all accepted triangles, and the reference's own walk (scene.h:50-110) returns exactly the same
-// hit if (1) it reaches k*'s leaf and (2) no second triangle is hit at exactly t*.  (1): the reference enters a node when
-// `!(min(t_exit, closest_t) < t_entry)` holds for it and all its ancestors, closest_t being whatever it is at that moment -
-// never below the final t*; the test is monotone in closest_t, so if every ancestor of k*'s leaf (leaf included) passes
-// with closest_t = t* it passes in the reference.  One fetch (the leaf's box, see VERIFY below) shows that for 99.7 % of the
-// hits; the rest evaluate these slab tests themselves (box_hit, the exact walk's arithmetic) from a per-leaf list of ancestor
-// node indices, leaf first, four nodes per step fetched in parallel, until a box holds the hit point with the margin - mostly
-// the parent or grandparent (1 M triangles: walking the whole list instead, root first: c5tile 1 455 -> 1 553 Msamples/s).
-// Measured and dropped: a certificate from the triangle's OWN bounds when the hit is accepted (no fetch; proves 97.3 % of the
-// hits): 1 515 against 1 553 - the leaf-box fetch rides on the SHADE step's latency anyway; 64-byte triangle records carrying
-// the leaf box (one line for test and certificate): 946.
-// (2): every triangle hit at t* is tested by the fast walk too, so a tie shows as `t == closest_t` there.  A ray for which
+// CERT (TRAVERSAL_CERTIFIED): the same walk made EXACT - under one stated premise.
+//   PREMISE (P).  Every triangle j whose Moller-Trumbore test (mt_hit = the reference's arithmetic) accepts the ray at a distance
+//   t_j inside [t_min, c] is TESTED by the fast walk while its closest_t is >= c: the slab tests of the fast walk pass for j's
+//   leaf child and for all its ancestors.  Geometrically that is what "conservative boxes" means; in floating point it needs
+//   the computed hit point o + t_j d to lie within the pad of j's box (2^-16 of the scene's scale, host/wide_bvh.cpp).  The
+//   computed t_j is off by at most about 2^-20 (|o - v0| + t_j) / kappa, kappa = |a| / (|e1| |e2|) (a = e1 . (d x e2), the
+//   determinant the test divides by; kappa = sin of the triangle's corner angle x cos of the incidence angle).  With origin and
+//   hit inside the scene (|o - v0| + t_j <= 2 S) that is within the pad for kappa >= 1 / 8: there (P) is PROVEN.  Below that
+//   floor - rays within about 7 degrees of a triangle's plane, slivers, needles; down at |a| ~ 1e-8 the reference itself accepts
+//   distances that are numerical noise - (P) is TESTED, NOT PROVEN: tools/certified_soak.py (sheets skimmed at 1e-7 .. 1e-3 rad, fences of needles with 1e-8 .. 1e-5 short
+//   edges, stacked layers of large triangles 1e-4 apart, a sloppy exporter's degenerate primitives, an outlier a million units
+//   away; 0 mismatches against the walk over the reference's tree), VERDICT r3's 750 000 adversarial rays (0 mismatches) and
+//   BASELINE configs[4] at its full 8.6 G samples (identical frames).
+//   Under (P) the fast walk's hit (t*, k*) is the global minimum over all accepted triangles, and the reference's own walk
+//   (scene.h:50-110) returns exactly the same hit if (1) it reaches k*'s leaf and (2) no second triangle is hit at exactly t*.
+// (1): the reference enters a node when `!(min(t_exit, closest_t) < t_entry)` holds for it and all its ancestors, closest_t being
+// whatever it is at that moment - never below the final t*; the test is monotone in closest_t, so if every ancestor of k*'s leaf
+// (leaf included) passes with closest_t = t* it passes in the reference.  One fetch (the leaf's box, see VERIFY below) shows
+// that for 99.7 % of the hits; the rest evaluate these slab tests themselves (box_hit, the exact walk's arithmetic) from a
+// per-leaf list of ancestor node indices, leaf first, four nodes per step fetched in parallel, until a box holds the hit point
+// with the margin - mostly the parent or grandparent.
+// (2): every triangle hit at t* is tested by the fast walk too (P), so a tie shows as `t == closest_t` there.  A ray for which
 // (1) or (2) cannot be shown - a grazed box, a shared edge, an origin outside the range the boxes were padded for - is walked
-// again by the reference's own walk (intersect_lane) inside this kernel: about one ray in 10^9.  No hit at all needs no
-// check: the reference can only accept triangles the fast walk would have found.
-// pending triangles tested per PRIM step (records fetched together): 1 / 2 / 3: c5tile 1 555 / 1 646 / 1 586, c5frame 2 248 / 2 339 / 2 277
-// Msamples/s (certified walk; 3 spills 9 registers).  Measured and dropped in the same spirit (one dependent fetch less per
-// step): the material record fetched together with the certificate's leaf box (+0.5 %: noise); the first dword of the node a
-// lane will fetch after its triangles requested at the NODE -> PRIM transition, so that the line arrives during the PRIM step
-// (-8 %: loads return in order, the PRIM step then waits for the node's miss as well)
+// again by the reference's own walk (intersect_lane) inside this kernel: about one ray in 10^5 on the 1 M-triangle scene.  No hit
+// at all needs no check: under (P) the reference can only accept triangles the fast walk would have found.
+// (What was measured on the way and dropped: EXPERIMENTS.md.)
 #ifndef PTMI_PRIM_BATCH
 #define PTMI_PRIM_BATCH 2
 #endif
