@@ -69,8 +69,9 @@ typedef struct {
     uint64_t seed_base;       /* 2023 */
     /* scheduling knob, results are independent of it: ray segments each path
      * advances per kernel launch before state returns to HBM and the active
-     * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default: 32, or the whole frame in one
-     * launch per chunk when a large scene's waves all but fit the device at once */
+     * queue is compacted (1 = pure wavefront, large = megakernel-like). 0 = default: 32 for the small LDS-resident
+     * scenes; scenes above 64 primitives render a frame as ONE launch of one wave per wave slot whose lanes take the
+     * next queued pixel when theirs is through, in the order of the last frame's per-pixel cost */
     int      segments_per_launch;
     int      collect_stats;   /* 1: also count rays / node visits / primitive tests (slower build of the kernel) */
     /* scheduling knob, results are independent of it: which 64 pixels share a wave.  0 = default (64x1 row strips),

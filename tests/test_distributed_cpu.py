@@ -235,3 +235,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     # a rank that fails must fail the whole run: an unknown flag makes every child exit non-zero
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_bench_keeps_torch_on_gloo():
+    """the only RCCL communicator of a bench.py process is libptmi's own; torch.distributed carries the 128-byte id
+    (and the rehearsals) on gloo, and the timed region's barrier / max over ranks go through ptmi_dist_barrier / ptmi_dist_allreduce_max."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'init_process_group("nccl"' not in src and "init_process_group('nccl'" not in src
+    assert 'init_process_group("gloo"' in src and "r.dist_barrier()" in src and "r.dist_allreduce_max(" in src
+    assert 'assert out["rccl_ranks"] == world' in src

@@ -9,7 +9,7 @@ shift || true
 CONFIGS=${*:-c2 c3 c5tile c5tile_packed c5tile_fast c5frame c5frame_packed c5frame_fast radiosity}
 for c in $CONFIGS; do
   if [ $c = radiosity ]; then bash tools/profile_rad.sh $TAG > gpurun_out/prof_rad_$TAG.log 2>&1 || { tail -20 gpurun_out/prof_rad_$TAG.log; exit 1; }; echo radiosity-done; continue; fi
-  f=1; case $c in c5tile*) f=2;; esac
+  f=1; case $c in c5tile*) f=3;; esac      # (the first frame after update_resolution runs in image order, the others in cost order)
   bash tools/profile.sh ${TAG}_$c $c $f > gpurun_out/prof_${TAG}_$c.log 2>&1 || { tail -20 gpurun_out/prof_${TAG}_$c.log; exit 1; }
   tail -1 gpurun_out/prof_${TAG}_$c.log | cut -c1-200
 done
