@@ -1023,7 +1023,8 @@ void renderFrames(ApplicationState& g, int n_frames, FrameStats* stats) {
     while (busy()) {
         for (int c = 0; c < r.n_chunks; c++) {
             Run& u = run[c]; RenderState::Chunk& ch = r.chunk[c];
-            while (!u.finished && u.issued - u.retired < kRunAhead) {
+            // (a refill launch takes the frame to its end: nothing to run ahead with)
+            while (!u.finished && u.issued - u.retired < (refill ? 1 : kRunAhead)) {
                 const int slot_out = u.issued % kRing;
                 CountPublish pub;
                 if (publish) {
