@@ -1422,6 +1422,40 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
     hipLaunchKernelGGL(ptmi_resolve, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tm, st, spp, rgb8, radiance, color_src);
 }
 
+// The proof of the certified walk for ONE hit (bounce_wide_body, VERIFY, in straight-line form): the hit point inside the hit leaf's
+// box of the reference's tree by eps, else the exact slab tests of the leaf's ancestors, leaf first, up to the first box that holds
+// the point with the margin.  false: a box of the chain failed - the reference's own walk has to decide this ray.
+__device__ __forceinline__ bool certified_proof(const DeviceScene& sc, f3 o, f3 d, float t_min, float closest_t, int slot_hit) {
+    const float4 lo = sc.wcert[2 * (size_t)slot_hit], hi = sc.wcert[2 * (size_t)slot_hit + 1];
+    const f3 q = o + closest_t * d;
+    const float kEps = 9.5367431640625e-7f, kSlope = 8.673617379884035e-19f;
+    const bool slopes = fabsf(d.x) >= kSlope && fabsf(d.y) >= kSlope && fabsf(d.z) >= kSlope;
+    const float ex = kEps * (fabsf(o.x) + fmaxf(fabsf(lo.x), fabsf(hi.x))), ey = kEps * (fabsf(o.y) + fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                ez = kEps * (fabsf(o.z) + fmaxf(fabsf(lo.z), fabsf(hi.z)));
+    const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
+    if (inside && slopes) return true;
+    const f3 rinv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));            // the reference's 1 / d for its slab tests
+    const uint32_t ref = __float_as_uint(lo.w);
+    uint32_t off = ref >> 5;
+    bool proven = false, failed = false;
+    for (int left = (int)(ref & 31u); left > 0 && !proven && !failed; left--, off++) {
+        const uint4 idx = sc.wanc[off];
+        const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];              // padding repeats the root
+            const float4 n0 = sc.nodes[2 * (size_t)j], n1 = sc.nodes[2 * (size_t)j + 1];
+            const float nx = kEps * (fabsf(o.x) + fmaxf(fabsf(n0.x), fabsf(n1.x))), ny = kEps * (fabsf(o.y) + fmaxf(fabsf(n0.y), fabsf(n1.y))),
+                        nz = kEps * (fabsf(o.z) + fmaxf(fabsf(n0.z), fabsf(n1.z)));
+            const bool holds = slopes && q.x - n0.x >= nx && n1.x - q.x >= nx && q.y - n0.y >= ny && n1.y - q.y >= ny && q.z - n0.z >= nz && n1.z - q.z >= nz;
+            const bool passes = box_hit(n0, n1, o, rinv, t_min, closest_t);
+            failed = failed || (!proven && !holds && !passes);
+            proven = proven || holds;
+        }
+    }
+    return !failed;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The certified closest hit of ONE ray, lane by lane (no phases): the walk and the proof of bounce_wide_body<..., CERT> in
 // straight-line form, for callers that trace a ray at a time (the Radiosity view).  Returns the REFERENCE's hit: its leaf-order
@@ -1479,40 +1513,7 @@ __device__ __forceinline__ bool certified_closest_hit(const DeviceScene& sc, uin
         g_base = st.child_base; g_bits = (st.imask << 8) | st.inner;
     }
     if (slot_hit < 0) return false;                        // the reference can only accept triangles this walk would have found
-    if (tie) return reference_walk();
-    // the proof (bounce_wide_body, VERIFY): the hit point inside the hit leaf's box of the reference's tree by eps, else the exact
-    // slab tests of the leaf's ancestors, leaf first, up to the first box that holds the point with the margin
-    const float4 lo = sc.wcert[2 * (size_t)slot_hit], hi = sc.wcert[2 * (size_t)slot_hit + 1];
-    const f3 q = o + closest_t * d;
-    const float kEps = 9.5367431640625e-7f, kSlope = 8.673617379884035e-19f;
-    const bool slopes = fabsf(d.x) >= kSlope && fabsf(d.y) >= kSlope && fabsf(d.z) >= kSlope;
-    {
-        const float ex = kEps * (fabsf(o.x) + fmaxf(fabsf(lo.x), fabsf(hi.x))), ey = kEps * (fabsf(o.y) + fmaxf(fabsf(lo.y), fabsf(hi.y))),
-                    ez = kEps * (fabsf(o.z) + fmaxf(fabsf(lo.z), fabsf(hi.z)));
-        const bool inside = q.x - lo.x >= ex && hi.x - q.x >= ex && q.y - lo.y >= ey && hi.y - q.y >= ey && q.z - lo.z >= ez && hi.z - q.z >= ez;
-        if (!(inside && slopes)) {
-            const f3 rinv = mk3(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));            // the reference's 1 / d for its slab tests
-            const uint32_t ref = __float_as_uint(lo.w);
-            uint32_t off = ref >> 5;
-            bool proven = false, failed = false;
-            for (int left = (int)(ref & 31u); left > 0 && !proven && !failed; left--, off++) {
-                const uint4 idx = sc.wanc[off];
-                const uint32_t ni[4] = {idx.x, idx.y, idx.z, idx.w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t j = ni[c] == 0xffffffffu ? 0u : ni[c];              // padding repeats the root
-                    const float4 n0 = sc.nodes[2 * (size_t)j], n1 = sc.nodes[2 * (size_t)j + 1];
-                    const float nx = kEps * (fabsf(o.x) + fmaxf(fabsf(n0.x), fabsf(n1.x))), ny = kEps * (fabsf(o.y) + fmaxf(fabsf(n0.y), fabsf(n1.y))),
-                                nz = kEps * (fabsf(o.z) + fmaxf(fabsf(n0.z), fabsf(n1.z)));
-                    const bool holds = slopes && q.x - n0.x >= nx && n1.x - q.x >= nx && q.y - n0.y >= ny && n1.y - q.y >= ny && q.z - n0.z >= nz && n1.z - q.z >= nz;
-                    const bool passes = box_hit(n0, n1, o, rinv, t_min, closest_t);
-                    failed = failed || (!proven && !holds && !passes);
-                    proven = proven || holds;
-                }
-            }
-            if (failed) return reference_walk();
-        }
-    }
+    if (tie || !certified_proof(sc, o, d, t_min, closest_t, slot_hit)) return reference_walk();
     t_hit = closest_t;
     ref_slot = sc.wref_slot[slot_hit];
     return true;
