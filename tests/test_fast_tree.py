@@ -530,3 +530,39 @@ def test_fast_tree_config5_rows(R):
     nd, rmse, mx = frame_diff(full, exact)
     print(f"config 5, whole 2048^2 frame at 16 spp, fast tree vs exact walk: {nd} of {W * H} pixels differ, max abs {mx:.3e}, RMSE {rmse:.3e}")
     assert rmse < 1e-4
+
+
+@pytest.mark.gpu
+def test_refill_launches_and_cost_order_do_not_change_a_frame(R):
+    """scenes above 64 primitives render a frame as ONE launch whose lanes take the next queued pixel when theirs is
+    through, and - from the second frame after update_resolution on - in the order of the last frame's per-pixel cost.  Three successive
+    frames (the RNG streams carry over) must equal, bit for bit, the same three frames rendered with both switched off (round 3's
+    launch chain), with the order alone switched off, and the oracle's; more pixels than lanes, so that lanes do take second pixels."""
+    args = tess(32, 16)                                   # 16 384 triangles
+    R.load_scene_arrays(*args)
+    assert R.set_traversal(-1) == R.CERTIFIED
+    W, H, spp, depth = 1024, 640, 3, 6                    # 655 360 pixels on 393 216 lanes
+    o = OracleScene.from_arrays(*args)
+    state = np.zeros((H * W, 6), np.uint32)
+    want = []
+    for f in range(3):
+        _, orad, _ = o.render(default_camera(), W, H, spp, max_depth=depth, rng_state=state, reset_rng=(f == 0))
+        want.append(orad)
+    saved = {k: os.environ.get(k) for k in ("PTMI_REFILL", "PTMI_ORDER")}
+    try:
+        for refill, order in (("1", None), ("1", "0"), ("0", "0"), ("1", "256")):
+            for k, v in (("PTMI_REFILL", refill), ("PTMI_ORDER", order)):
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+            R.set_config(spp=spp, max_depth=depth, collect_stats=False, segments_per_launch=0)
+            R.update_resolution(W, H)
+            for f in range(3):
+                st = R.render_frame()
+                _, rad = R.read_image()
+                nd = int((bits(rad) != bits(want[f])).any(axis=-1).sum())
+                assert nd == 0, f"refill {refill} order {order} frame {f}: {nd} pixels differ from the oracle"
+                if refill == "1": assert st.bounce_launches == 1
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
