@@ -23,11 +23,16 @@ def read():
     return buf[:min(n, cap)].copy()
 for v in variants:
     budget, sparse = v.split(":")
-    os.environ["PTMI_REFILL"] = "1" if sparse.endswith("r") else "0"
+    os.environ["PTMI_REFILL"] = "1" if "r" in sparse else "0"
+    os.environ.pop("PTMI_ORDER", None)
     r.set_config(spp=spp, max_depth=8, collect_stats=False)
     r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
     r.render_frame(); read()
-    r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
+    if "o" in sparse:                                   # 'o': successive frames, so that the traced one runs in the order of the last one's costs
+        r.render_frame(); read()
+    else:
+        os.environ["PTMI_ORDER"] = "0"
+        r.update_resolution(2048, 2048, n_ranks=share, rank=min(3, share - 1), row_block=8)
     t0 = time.perf_counter(); st = r.render_frame(); dt = time.perf_counter() - t0
     w = read().astype(np.int64)
     half = w[:, 11] >> 8; w[:, 11] &= 0xff
@@ -47,6 +52,9 @@ for v in variants:
     print("  starting lanes per resident wave: " + " ".join(f"{x:.0f}" for x in lanes))
     hs = np.sort(np.where(half > 0, start + half, end)) * 1e-5
     print("  time (ms) by which 10 / 25 / 50 / 75 / 90 / 99 % of the waves were less than half full: " + " ".join(f"{hs[int(q * (len(hs) - 1))]:.2f}" for q in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99)))
+    live = np.where(half > 0, half, w[:, 1])
+    print(f"  wave time before / after a wave is less than half full: {live.sum() / w[:, 1].sum():.3f} / {1 - live.sum() / w[:, 1].sum():.3f}; after the queue ran dry (first wave end) "
+          f"{np.clip(end - end.min(), 0, None).sum() / w[:, 1].sum():.3f} of the wave time")
     print(f"  mean resident waves {(w[:, 1].sum() / (T * 1e5)):.0f}; wave duration mean {w[:, 1].mean()*1e-2:.0f} us, max {w[:, 1].max()*1e-2:.0f} us")
     names = ["NODE", "PRIM", "SHADE"]
     tot_clk = sum(w[:, 8 + k].sum() * 16 for k in range(3))
