@@ -126,8 +126,8 @@ CONFIGS = {
     "c5_full": dict(scene="tess1m", width=2048, height=2048, spp=2048, max_depth=8, tiling=None, kernel="ptmi_bounce_wide", counter_spp=64,
                     profile_of="c5frame", served_from="l2/mall/hbm",
                     what="BASELINE configs[4] at its stated size - 2048x2048, 2048 spp = 8.6 G samples - the WHOLE frame on one GPU, default = certified walk"),
-    "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce",
-               served_from="lds", what="BASELINE configs[3]"),
+    "c4": dict(scene="cbox.obj", width=4096, height=4096, spp=512, max_depth=5, tiling=None, kernel="ptmi_bounce", counter_spp=64,
+               served_from="lds", what="BASELINE configs[3] at its stated size - 8.6 G samples - on one GPU"),
     "c5strong": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_wide",
                      served_from="l2/mall/hbm", what="BASELINE configs[4] at 64 of its 2048 spp (default = certified walk: the reference's frame)"),
     "c5strong_packed": dict(scene="tess1m", width=2048, height=2048, spp=64, max_depth=8, tiling=None, kernel="ptmi_bounce_phased", traversal=4,
@@ -551,7 +551,7 @@ def main():
         extras = []
         loaded = None
         t_extras = time.perf_counter()
-        for xname, xsteps in (("c3", 3), ("c5tile", 6), ("c5tile_full", 2), ("c5tile_packed", 6), ("c5tile_fast", 6), ("c5frame", 3), ("c5_full", 1),
+        for xname, xsteps in (("c3", 3), ("c4", 1), ("c5tile", 6), ("c5tile_full", 2), ("c5tile_packed", 6), ("c5tile_fast", 6), ("c5frame", 3), ("c5_full", 1),
                               ("c5frame_packed", 2), ("c5frame_fast", 3)):
             t_x = time.perf_counter()
             if t_x - t_extras > args.extra_budget:        # wall-clock guard: the line must come out whatever a box does
@@ -582,7 +582,7 @@ def main():
                                     "(certified walk: every hit is proven to be the one the reference's walk returns, or walked by that walk - "
                                     "identical whenever the proof's stated precondition holds, DESIGN.md 4.9 - and measured here; fast tree: bar RMSE < 1e-4)"}
                 allocate(xcfg)
-            xwarm = 0 if xname == "c5_full" else 1     # (its two counter frames have warmed everything a 3 s frame can warm)
+            xwarm = 0 if xname in ("c5_full", "c4") else 1     # (their two counter frames have warmed everything a 1 - 3 s frame can warm)
             xm = measure(r, xcfg, xsteps, xwarm, run_steps, barrier, 0, reduce_max, pipelined)
             xsamples = xm["local_samples_per_step"] * xsteps
             tiled = f", rank {xcfg['tiling'][1]} of {xcfg['tiling'][0]}" if xcfg["tiling"] else ""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # All profiles of a round on one GPU box: tools/profile_all.sh [tag=all] [configs...]  ->  gpurun_out/prof_<tag>_<config>/, gpurun_out/prof_rad_<tag>/
-# (configs: any of c2 c3 c5tile c5tile_packed c5tile_fast c5frame c5frame_packed c5frame_fast radiosity; default: all - more than one gpurun call's 20 minutes)
+# (configs: any of c2 c3 c4 c5tile c5tile_packed c5tile_fast c5frame c5frame_packed c5frame_fast radiosity; default: all - more than one gpurun call's 20 minutes)
 # (copy pmc_<config>.json -> profiles/rNN_pmc_<config>.json and trace/trace_kernel_stats.csv -> profiles/rNN_kernel_stats_<config>.csv)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 set -e
