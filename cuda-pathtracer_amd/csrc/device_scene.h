@@ -71,7 +71,8 @@ struct DeviceScene {
     // TRAVERSAL_CERTIFIED: what the VERIFY phase and the fallback read (kernels.hip: bounce_wide_body, CERT)
     const uint4* wanc = nullptr;       // per reference leaf: its ancestors' pre-order node indices (leaf included), 4 per chunk, 0xffffffff pads
     const float4* wqprims = nullptr;   // scenes with quads: 64-byte records (v0 | type, e1, e2, e3) in the fast tree's order instead of wprims
-    const float4* wcert = nullptr;     // per fast-order triangle: (leaf box min, bits(first chunk << 5 | chunks of the leaf's list)) (leaf box max, 0)
+    const float4* wcert = nullptr;     // kWideCertStride float4 per fast-order triangle, one 64-byte line per hit: (leaf box min, bits(first chunk << 5 |
+                                       // chunks of the leaf's list)) (leaf box max, 0) (wmats' entry) (0)
     float w_big = 0.0f;                // the scene's scale (host/wide_bvh.h: WideBVH::scale); informational since the certificate takes eps from each box
     int w_cert_debug = 0;              // test hook of the solver's certified walk: 1 every blocked ray takes the ancestor chain, 2 the reference's walk
     const int* wfast_of_ref = nullptr; // reference leaf-order slot -> fast order

@@ -494,11 +494,11 @@ __device__ __forceinline__ f3 sample_mis(const float* __restrict__ g, f3 normal,
 // GUIDED: the grid / MIS branches of integrator.h:232-263 are compiled in (sampling_mode != SAMPLING_BSDF with CDF
 // records present); the plain BSDF instantiation carries none of that code.
 // Material record of leaf-order slot k: plain layout mats[3k..3k+2], packed layout (normal, table row) + (Kd, Ke) table.
-struct MatSource { const float4* mats; const float4* mtab; const int* load_index; };
+struct MatSource { const float4* mats; const float4* mtab; const int* load_index; int stride = 1; };      // PACKED: entry k at mats[k * stride]
 template <bool PACKED>
 __device__ __forceinline__ void fetch_material(const MatSource& ms, int k, f3& n, f3& bsdf, f3& Le, int& row) {
     if (PACKED) {
-        const float4 m = ms.mats[k];
+        const float4 m = ms.mats[(size_t)k * ms.stride];
         n = xyz(m); row = __float_as_int(m.w);
         bsdf = xyz(ms.mtab[2 * row]); Le = xyz(ms.mtab[2 * row + 1]);
     } else {
@@ -935,7 +935,8 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     auto u4 = [](u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); };
     const LdsU4* top_lds = (const LdsU4*)top;
     const GlobalU4* wnodes_g = (const GlobalU4*)a.sc.wnodes;
-    const MatSource ms = MatSource{a.sc.wmats, a.sc.wmtab, a.sc.wload_index};
+    // (the certified walk shades from the line its proof has just read: DeviceScene::wcert)
+    const MatSource ms = CERT ? MatSource{a.sc.wcert + 2, a.sc.wmtab, a.sc.wload_index, kWideCertStride} : MatSource{a.sc.wmats, a.sc.wmtab, a.sc.wload_index, 1};
     if (GUIDED) fill_grid_solid_angles();
 
     int slot = active ? (a.queue_in ? a.queue_in[idx] : idx) : 0;
@@ -970,6 +971,9 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
     auto origin_in_range = [&]() { return fmaxf(fabsf(p.o.x), fmaxf(fabsf(p.o.y), fabsf(p.o.z))) <= a.sc.w_guard; };
     if (CERT && alive && !origin_in_range()) phase = PH_EXACT;
 
+#ifdef PTMI_WALK_CAP
+    int walk_cap_n = 0;
+#endif
     while (true) {
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_prim = __popcll(__ballot(phase == PH_PRIM));
@@ -1070,7 +1074,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                     // Then every entry distance comes out <= t*, every exit distance >= t*, and `!(min(exit, closest_t) < entry)`
                     // holds whatever closest_t >= t* the reference carries there.  A direction component below 2^-60 (1 / d near
                     // overflow) or a point within eps of a face goes to the chain of exact slab tests instead.
-                    const float4 lo = a.sc.wcert[2 * (size_t)slot_hit], hi = a.sc.wcert[2 * (size_t)slot_hit + 1];
+                    const float4 lo = a.sc.wcert[kWideCertStride * (size_t)slot_hit], hi = a.sc.wcert[kWideCertStride * (size_t)slot_hit + 1];
                     const f3 q = p.o + closest_t * p.d;
                     // eps from THIS box's own coordinates M_a = max(|lo_a|, |hi_a|) (round 3 took the scene's largest coordinate: one
                     // far-away primitive then sent every hit of the scene to the chain).  A point inside the box has |Q_a| <= M_a and
@@ -1087,6 +1091,7 @@ __device__ __forceinline__ void bounce_wide_body(const BounceArgs& a) {
                         g_base = ref >> 5; t_base = ref & 31u;
                         inv = mk3(rcp_rn(p.d.x), rcp_rn(p.d.y), rcp_rn(p.d.z));       // the reference's 1 / d for its slab tests
                         if (STATS) cn.cert_chain++;
+                        if (t_base == 0u) phase = PH_EXACT;                         // (no list: never built that way; the count below must not wrap)
                     }
                 } else if (phase == PH_VERIFY) {
                     const uint4 idx = a.sc.wanc[g_base];
@@ -1426,7 +1431,7 @@ void launch_resolve(const TileMap& tm, const PathState& st, int spp, unsigned ch
 // box of the reference's tree by eps, else the exact slab tests of the leaf's ancestors, leaf first, up to the first box that holds
 // the point with the margin.  false: a box of the chain failed - the reference's own walk has to decide this ray.
 __device__ __forceinline__ bool certified_proof(const DeviceScene& sc, f3 o, f3 d, float t_min, float closest_t, int slot_hit) {
-    const float4 lo = sc.wcert[2 * (size_t)slot_hit], hi = sc.wcert[2 * (size_t)slot_hit + 1];
+    const float4 lo = sc.wcert[kWideCertStride * (size_t)slot_hit], hi = sc.wcert[kWideCertStride * (size_t)slot_hit + 1];
     const f3 q = o + closest_t * d;
     const float kEps = 9.5367431640625e-7f, kSlope = 8.673617379884035e-19f;
     const bool slopes = fabsf(d.x) >= kSlope && fabsf(d.y) >= kSlope && fabsf(d.z) >= kSlope;

@@ -244,7 +244,7 @@ __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, u
                 const float tq = min_raw(mt_candidate(xyz(q[0]), xyz(q[1]), xyz(q[2]), o, d, eps_up, 1e-5f), mt_candidate(xyz(q[0]), xyz(q[2]), xyz(q[3]), o, d, eps_up, 1e-5f));
                 if (!(tq < max_dist)) continue;
                 if (!CERT) return true;
-                const float4 c_lo = sc.wcert[2 * (size_t)k], c_hi = sc.wcert[2 * (size_t)k + 1];
+                const float4 c_lo = sc.wcert[kWideCertStride * (size_t)k], c_hi = sc.wcert[kWideCertStride * (size_t)k + 1];
                 return certified_blocked<CERT, QUADS>(sc, c_lo, c_hi, tq, o, d, max_dist, slot_a, slot_b, chain);
             }
             const float* r = sc.wprims + 9 * (size_t)k;
@@ -264,7 +264,7 @@ __device__ __forceinline__ bool visibility_blocked_wide(const DeviceScene& sc, u
             if ((m >= 0.0f) & (t <= max_dist)) {
                 if (!CERT) return true;
                 // (fetching the leaf box together with the triangle record, before the test: no gain - n = 8192: 84.0 vs 84.4 ms)
-                const float4 c_lo = sc.wcert[2 * (size_t)k], c_hi = sc.wcert[2 * (size_t)k + 1];
+                const float4 c_lo = sc.wcert[kWideCertStride * (size_t)k], c_hi = sc.wcert[kWideCertStride * (size_t)k + 1];
                 return certified_blocked<CERT, QUADS>(sc, c_lo, c_hi, t, o, d, max_dist, slot_a, slot_b, chain);
             }
         }

@@ -37,6 +37,7 @@
 namespace ptmi {
 
 constexpr int kWideNodeDwords = 32;
+constexpr int kWideCertStride = 4;                // float4 per triangle in DeviceScene::wcert (proof record + shading record: one 64-byte line)
 constexpr int WN_PLANES0 = 8, WN_WORD0 = 20;      // first dword of the quantised planes / of the per-slot result words
 constexpr int kWideMaxLeaf = 3;                   // triangles per leaf child (3 bits of a 24-bit triangle word per node)
 constexpr float kWideInvLimit = 1.2089258e24f;    // 2^80: |1 / d| is clamped here, so no plane distance is ever inf or NaN

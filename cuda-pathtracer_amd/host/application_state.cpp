@@ -413,13 +413,17 @@ void SceneState::buildFast() {
         if (fits && bvh_depth <= 62) {
             std::vector<int> leaf_of_slot((size_t)n, 0), fast_of_ref((size_t)n, 0);
             for (int i = 0; i < nn; i++) if (bvh_nodes[i].isLeaf()) for (int k = 0; k < bvh_nodes[i].prim_count; k++) leaf_of_slot[bvh_nodes[i].left_child + k] = i;
-            std::vector<float4> cert((size_t)2 * n);           // the leaf's box as the reference built it + where its ancestor list is
+            // one 64-byte record per fast-order triangle - ONE line of memory per hit: the leaf's box as the reference built it + where
+            // its ancestor list is (the proof reads these), then what shading reads (wmats' entry: normal, row of the material table)
+            std::vector<float4> cert((size_t)kWideCertStride * n);
             for (int k = 0; k < n; k++) {
                 const int leaf = leaf_of_slot[ref_slot[k]];
                 const AABB& bx = bvh_nodes[leaf].bbox;
                 float ref_bits; std::memcpy(&ref_bits, &leaf_ref[leaf], 4);
-                cert[(size_t)2 * k] = make_float4(bx.min.x, bx.min.y, bx.min.z, ref_bits);
-                cert[(size_t)2 * k + 1] = make_float4(bx.max.x, bx.max.y, bx.max.z, 0.0f);
+                cert[(size_t)kWideCertStride * k] = make_float4(bx.min.x, bx.min.y, bx.min.z, ref_bits);
+                cert[(size_t)kWideCertStride * k + 1] = make_float4(bx.max.x, bx.max.y, bx.max.z, 0.0f);
+                cert[(size_t)kWideCertStride * k + 2] = wm[k];
+                cert[(size_t)kWideCertStride * k + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 fast_of_ref[ref_slot[k]] = k;
             }
             d_wanc = (uint4*)upload_vec(anc.data(), anc.size() * sizeof(uint32_t), "d_wanc");
