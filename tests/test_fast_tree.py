@@ -566,3 +566,17 @@ def test_refill_launches_and_cost_order_do_not_change_a_frame(R):
         for k, v in saved.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_node_test_on_the_device_equals_the_hosts(tmp_path):
+    """csrc/wide_bvh.h's wide_node_test is ONE function compiled for both sides (the host walk of the 8-wide tree is the builder's own
+    check); tools/node_test_check.hip runs it on 65 536 random nodes and rays on the device and on the host and compares every field."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "node_test_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "cuda-pathtracer_amd", "csrc"),
+                    "-o", exe, os.path.join(root, "tools", "node_test_check.hip")], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "mismatches: child_base 0 tri_base 0 imask 0 inner 0 tris 0" in out.stdout, out.stdout + out.stderr

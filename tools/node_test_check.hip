@@ -11,7 +11,7 @@ __global__ void k(const uint4* nodes, const float* rays, WideStep* out, int n) {
     const f3 o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     const f3 d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
-    out[i] = wide_node_test(q[0], q[2], q[3], q[4], q[5], q[6], o, inv, wide_octinv(inv), 1e-4f, 3.0e38f);
+    out[i] = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], o, inv, wide_octinv(inv), 1e-4f, 3.0e38f);
 }
 int main() {
     const int n = 1 << 16;
@@ -36,7 +36,7 @@ int main() {
         const uint4* q = (const uint4*)&nodes[(size_t)i * 32];
         const f3 o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
         const f3 inv = mk3(wide_inv(d.x), wide_inv(d.y), wide_inv(d.z));
-        const WideStep w = wide_node_test(q[0], q[2], q[3], q[4], q[5], q[6], o, inv, wide_octinv(inv), 1e-4f, 3.0e38f);
+        const WideStep w = wide_node_test(q[0], q[1], q[2], q[3], q[4], q[5], q[6], o, inv, wide_octinv(inv), 1e-4f, 3.0e38f);
         bad[0] += w.child_base != got[i].child_base; bad[1] += w.tri_base != got[i].tri_base; bad[2] += w.imask != got[i].imask;
         bad[3] += w.inner != got[i].inner; bad[4] += w.tris != got[i].tris; hits += w.tris != 0 || w.inner != 0;
         if (i < 2) printf("host %08x %08x %02x %02x %06x | dev %08x %08x %02x %02x %06x\n", w.child_base, w.tri_base, w.imask, w.inner, w.tris, got[i].child_base, got[i].tri_base, got[i].imask, got[i].inner, got[i].tris);
