@@ -617,7 +617,7 @@ def main():
             try:
                 xcfg = dict(CONFIGS[xname])
                 if args.rehearse_gloo or args.rehearse_shared_gpu:     # rehearsal on one shared GPU: same control flow, small frames
-                    xcfg.update(width=256, height=256, spp=4)
+                    xcfg.update(width=256, height=256, spp=4); xcfg.pop("counter_spp", None)
                 if xcfg["scene"] != loaded:
                     load_scene(r, xcfg["scene"] if not (shared and xcfg["scene"] == "tess1m") else "cbox.obj"); loaded = xcfg["scene"]
                 r.update_resolution(xcfg["width"], xcfg["height"], n_ranks=world, rank=rank, row_block=8)
